@@ -1,0 +1,745 @@
+// Device context: owns the GPU copies of a scene, the wavefront workspace and
+// the stream, validates what is uploaded, and drives the kernels of kernels.hip.
+// Implements the device half of include/raytracer_amd.h.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace rta {
+
+void set_global_error(const std::string &text);      // api.cpp
+const char *get_global_error();
+
+namespace {
+
+constexpr uint32_t kLeaf = 0x80000000u;
+constexpr uint32_t kSphereFlag = 1u, kLastFlag = 2u;
+constexpr int kMaxDepth = 64;             // the reference's traversal stack (src/main.cpp:339)
+constexpr int kTile = 8;                  // pixels per tile side; 64 pixels = one wave64
+
+struct DeviceBuffer {
+	void *ptr = nullptr;
+	size_t bytes = 0;
+
+	~DeviceBuffer() { release(); }
+	void release()
+	{
+		if (ptr)
+			(void)hipFree(ptr);
+		ptr = nullptr;
+		bytes = 0;
+	}
+	// grow-only
+	hipError_t reserve(size_t want)
+	{
+		if (want <= bytes)
+			return hipSuccess;
+		release();
+		hipError_t e = hipMalloc(&ptr, want);
+		if (e == hipSuccess)
+			bytes = want;
+		return e;
+	}
+	template <typename T>
+	T *as() const { return static_cast<T *>(ptr); }
+};
+
+}  // namespace
+
+}  // namespace rta
+
+using namespace rta;
+
+struct rta_context {
+	int device = -1;
+	hipStream_t stream = nullptr;
+	std::string error;
+
+	// scene
+	bool have_scene = false;
+	DeviceBuffer pairs, prims, shade_prims, materials, lights;
+	uint32_t root_ref = 0;
+	int stack_depth = 1;
+	int32_t n_prims = 0, n_lights = 0;
+
+	// wavefront workspace
+	DeviceBuffer ray0, ray1, hit, thr, col, acc, q_ray0, q_ray1, q_regen, shadow, partial, pixels, frame, bgr, counters;
+	DeviceBuffer io_a, io_b, io_c;       // staging for host-pointer calls
+	Counters *host_counters = nullptr;    // pinned
+
+	int fail(int code, const std::string &text)
+	{
+		error = text;
+		return code;
+	}
+	int hip_fail(hipError_t e, const char *what)
+	{
+		error = std::string(what) + ": " + hipGetErrorString(e);
+		return RTA_E_DEVICE;
+	}
+};
+
+#define HIP_TRY(ctx, call)                                                  \
+	do {                                                                    \
+		hipError_t e__ = (call);                                            \
+		if (e__ != hipSuccess)                                              \
+			return (ctx)->hip_fail(e__, #call);                             \
+	} while (0)
+
+extern "C" {
+
+int rta_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess)
+		return 0;
+	return n;
+}
+
+int rta_create(int device, rta_context **out)
+{
+	if (!out)
+		return RTA_E_INVALID;
+	*out = nullptr;
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n <= 0 || device < 0 || device >= n) {
+		set_global_error(e != hipSuccess
+		                     ? std::string("hipGetDeviceCount: ") + hipGetErrorString(e)
+		                     : "no such GPU device " + std::to_string(device) + " (" + std::to_string(n) + " present)");
+		return RTA_E_NO_DEVICE;
+	}
+	hipDeviceProp_t prop;
+	if ((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device)) != hipSuccess) {
+		set_global_error(std::string("hipSetDevice: ") + hipGetErrorString(e));
+		return RTA_E_NO_DEVICE;
+	}
+	if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+		set_global_error(std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only");
+		return RTA_E_NO_DEVICE;
+	}
+	rta_context *ctx = new rta_context();
+	ctx->device = device;
+	if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+	    (e = hipHostMalloc((void **)&ctx->host_counters, sizeof(Counters), hipHostMallocDefault)) != hipSuccess ||
+	    (e = ctx->counters.reserve(sizeof(Counters))) != hipSuccess) {
+		set_global_error(std::string("context set-up: ") + hipGetErrorString(e));
+		rta_destroy(ctx);
+		return RTA_E_DEVICE;
+	}
+	*out = ctx;
+	return RTA_OK;
+}
+
+void rta_destroy(rta_context *ctx)
+{
+	if (!ctx)
+		return;
+	(void)hipSetDevice(ctx->device);
+	if (ctx->stream) {
+		(void)hipStreamSynchronize(ctx->stream);
+		(void)hipStreamDestroy(ctx->stream);
+	}
+	if (ctx->host_counters)
+		(void)hipHostFree(ctx->host_counters);
+	delete ctx;
+}
+
+const char *rta_last_error(const rta_context *ctx) { return ctx ? ctx->error.c_str() : get_global_error(); }
+
+void *rta_stream(rta_context *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ upload
+
+namespace {
+
+struct Flattened {
+	std::vector<float4> pairs, prims, shade, mats, lights;
+	uint32_t root = 0;
+	int depth = 0;
+};
+
+inline float as_float(uint32_t u)
+{
+	float f;
+	memcpy(&f, &u, 4);
+	return f;
+}
+
+// Checks everything the kernels take for granted and builds their layouts.
+// Returns an empty string on success, else what is wrong.
+std::string flatten(const rta_scene_desc &d, Flattened &out)
+{
+	if (d.n_prims <= 0 || d.n_nodes <= 0 || d.n_materials <= 0 || d.n_lights < 0)
+		return "scene needs at least one primitive, one node and one material";
+	if (!d.prim_type || !d.prim_material || !d.prim_light || !d.prim_geom || !d.prim_normals || !d.node_bounds ||
+	    !d.node_index || !d.node_count || !d.materials || (d.n_lights && (!d.light_color || !d.light_prim)))
+		return "scene description has null arrays";
+	if ((uint32_t)d.n_prims >= kLeaf || (uint32_t)d.n_nodes >= kLeaf)
+		return "too many primitives or nodes";
+
+	for (int32_t k = 0; k < d.n_prims; k++) {
+		if (d.prim_type[k] != RTA_PRIM_TRIANGLE && d.prim_type[k] != RTA_PRIM_SPHERE)
+			return "primitive " + std::to_string(k) + ": unknown type";
+		if (d.prim_material[k] < 0 || d.prim_material[k] >= d.n_materials)
+			return "primitive " + std::to_string(k) + ": material index out of range";
+		if (d.prim_light[k] < -1 || d.prim_light[k] >= d.n_lights)
+			return "primitive " + std::to_string(k) + ": light index out of range";
+	}
+	for (int32_t l = 0; l < d.n_lights; l++) {
+		int32_t p = d.light_prim[l];
+		if (p < 0 || p >= d.n_prims)
+			return "light " + std::to_string(l) + ": primitive index out of range";
+		if (d.prim_type[p] != RTA_PRIM_TRIANGLE)
+			return "light " + std::to_string(l) + ": only triangles emit (src/parser.cpp:297-300)";
+	}
+
+	// Walk the tree from the root: every node reached once, children adjacent,
+	// leaves partition [0, n_prims), depth within the traversal stack.
+	std::vector<int32_t> pair_of(d.n_nodes, -1);      // inner node -> pair record
+	std::vector<uint8_t> covered(d.n_prims, 0);
+	std::vector<uint8_t> last_flag(d.n_prims, 0);
+	struct Item {
+		int32_t node, depth;
+	};
+	std::vector<Item> todo;
+	std::vector<int32_t> inner_order;
+	todo.push_back({0, 0});
+	int64_t visited = 0;
+	int max_depth = 0;
+	while (!todo.empty()) {
+		Item it = todo.back();
+		todo.pop_back();
+		if (++visited > d.n_nodes)
+			return "node graph is not a tree (a node is reachable twice)";
+		max_depth = std::max(max_depth, it.depth);
+		int32_t idx = d.node_index[it.node], cnt = d.node_count[it.node];
+		if (cnt > 0) {
+			if (idx < 0 || (int64_t)idx + cnt > d.n_prims)
+				return "leaf " + std::to_string(it.node) + ": primitive range out of bounds";
+			for (int32_t k = idx; k < idx + cnt; k++) {
+				if (covered[k])
+					return "primitive " + std::to_string(k) + " belongs to two leaves";
+				covered[k] = 1;
+			}
+			last_flag[idx + cnt - 1] = 1;
+		} else {
+			if (cnt < 0)
+				return "node " + std::to_string(it.node) + ": negative count";
+			if (idx <= 0 || (int64_t)idx + 1 >= d.n_nodes)
+				return "node " + std::to_string(it.node) + ": child index out of range";
+			if (pair_of[it.node] >= 0)
+				return "node graph is not a tree";
+			pair_of[it.node] = (int32_t)inner_order.size();
+			inner_order.push_back(it.node);
+			// second child first so that the first child is numbered next (depth-first, first child first)
+			todo.push_back({idx + 1, it.depth + 1});
+			todo.push_back({idx, it.depth + 1});
+		}
+	}
+	if (max_depth > kMaxDepth)
+		return "tree depth " + std::to_string(max_depth) + " exceeds the traversal stack of " + std::to_string(kMaxDepth);
+	// primitives outside every leaf are unreachable, which is legal for a
+	// caller-made tree but would leave their records without a leaf terminator
+	out.depth = std::max(max_depth, 1);
+
+	auto ref_of = [&](int32_t node) -> uint32_t {
+		return d.node_count[node] > 0 ? (kLeaf | (uint32_t)d.node_index[node]) : (uint32_t)pair_of[node];
+	};
+	out.root = ref_of(0);
+	out.pairs.resize(std::max<size_t>(inner_order.size(), 1) * 4, make_float4(0, 0, 0, 0));
+	for (size_t p = 0; p < inner_order.size(); p++) {
+		int32_t l = d.node_index[inner_order[p]], r = l + 1;
+		const float *a = d.node_bounds + (size_t)l * 6, *b = d.node_bounds + (size_t)r * 6;
+		out.pairs[p * 4 + 0] = make_float4(a[0], a[1], a[2], a[3]);
+		out.pairs[p * 4 + 1] = make_float4(a[4], a[5], b[0], b[1]);
+		out.pairs[p * 4 + 2] = make_float4(b[2], b[3], b[4], b[5]);
+		out.pairs[p * 4 + 3] = make_float4(as_float(ref_of(l)), as_float(ref_of(r)), 0, 0);
+	}
+
+	out.prims.resize((size_t)d.n_prims * 3);
+	out.shade.resize((size_t)d.n_prims * 3);
+	for (int32_t k = 0; k < d.n_prims; k++) {
+		const float *g = d.prim_geom + (size_t)k * 9, *nn = d.prim_normals + (size_t)k * 9;
+		// an uncovered primitive terminates its own (never visited) leaf
+		uint32_t flags = (last_flag[k] || !covered[k]) ? kLastFlag : 0;
+		if (d.prim_type[k] == RTA_PRIM_SPHERE) {
+			flags |= kSphereFlag;
+			out.prims[(size_t)k * 3 + 0] = make_float4(g[0], g[1], g[2], as_float(flags));
+			out.prims[(size_t)k * 3 + 1] = make_float4(g[3], 0, 0, 0);
+			out.prims[(size_t)k * 3 + 2] = make_float4(0, 0, 0, 0);
+		} else {
+			// e0 = v0 - v2, e1 = v1 - v2 (src/main.cpp:252-253), rounded once in fp32
+			out.prims[(size_t)k * 3 + 0] = make_float4(g[6], g[7], g[8], as_float(flags));
+			out.prims[(size_t)k * 3 + 1] = make_float4(g[0] - g[6], g[1] - g[7], g[2] - g[8], 0);
+			out.prims[(size_t)k * 3 + 2] = make_float4(g[3] - g[6], g[4] - g[7], g[5] - g[8], 0);
+		}
+		out.shade[(size_t)k * 3 + 0] = make_float4(nn[0], nn[1], nn[2], as_float((uint32_t)d.prim_material[k]));
+		out.shade[(size_t)k * 3 + 1] = make_float4(nn[3], nn[4], nn[5], as_float((uint32_t)d.prim_light[k]));
+		out.shade[(size_t)k * 3 + 2] = make_float4(nn[6], nn[7], nn[8], as_float((uint32_t)d.prim_type[k]));
+	}
+	out.mats.resize((size_t)d.n_materials * 2);
+	for (int32_t m = 0; m < d.n_materials; m++) {
+		const float *s = d.materials + (size_t)m * 6;
+		out.mats[(size_t)m * 2 + 0] = make_float4(s[0], s[1], s[2], s[3]);
+		out.mats[(size_t)m * 2 + 1] = make_float4(s[4], s[5], 0, 0);
+	}
+	out.lights.resize(std::max<size_t>((size_t)d.n_lights, 1) * 7, make_float4(0, 0, 0, 0));
+	for (int32_t l = 0; l < d.n_lights; l++) {
+		int32_t p = d.light_prim[l];
+		const float *c = d.light_color + (size_t)l * 3;
+		const float *g = d.prim_geom + (size_t)p * 9, *nn = d.prim_normals + (size_t)p * 9;
+		float4 *L = &out.lights[(size_t)l * 7];
+		L[0] = make_float4(c[0], c[1], c[2], as_float((uint32_t)p));
+		for (int q = 0; q < 3; q++) {
+			L[1 + q] = make_float4(g[q * 3], g[q * 3 + 1], g[q * 3 + 2], 0);
+			L[4 + q] = make_float4(nn[q * 3], nn[q * 3 + 1], nn[q * 3 + 2], 0);
+		}
+	}
+	return "";
+}
+
+template <typename T>
+int upload_vec(rta_context *ctx, DeviceBuffer &buf, const std::vector<T> &v)
+{
+	HIP_TRY(ctx, buf.reserve(v.size() * sizeof(T)));
+	HIP_TRY(ctx, hipMemcpyAsync(buf.ptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+	return RTA_OK;
+}
+
+TreeRef tree_of(const rta_context *ctx)
+{
+	return TreeRef{ctx->pairs.as<const float4>(), ctx->prims.as<const float4>(), ctx->root_ref};
+}
+
+// Owned pixels in walk order: tiles row-major, pixels row-major inside a tile,
+// clipped to the frame.
+void shard_pixels(int32_t w, int32_t h, int32_t shard, int32_t n_shards, std::vector<int32_t> &out)
+{
+	out.clear();
+	const int32_t tx = (w + kTile - 1) / kTile, ty = (h + kTile - 1) / kTile;
+	for (int32_t t = 0; t < tx * ty; t++) {
+		if (t % n_shards != shard)
+			continue;
+		const int32_t x0 = (t % tx) * kTile, y0 = (t / tx) * kTile;
+		for (int32_t y = y0; y < std::min(y0 + kTile, h); y++)
+			for (int32_t x = x0; x < std::min(x0 + kTile, w); x++)
+				out.push_back(y * w + x);
+	}
+}
+
+}  // namespace
+
+extern "C" {
+
+int rta_upload_scene(rta_context *ctx, const rta_scene_desc *desc)
+{
+	if (!ctx)
+		return RTA_E_INVALID;
+	if (!desc)
+		return ctx->fail(RTA_E_INVALID, "null scene description");
+	Flattened f;
+	std::string problem = flatten(*desc, f);
+	if (!problem.empty())
+		return ctx->fail(RTA_E_INVALID, "invalid scene: " + problem);
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	ctx->have_scene = false;
+	int rc;
+	if ((rc = upload_vec(ctx, ctx->pairs, f.pairs)) || (rc = upload_vec(ctx, ctx->prims, f.prims)) ||
+	    (rc = upload_vec(ctx, ctx->shade_prims, f.shade)) || (rc = upload_vec(ctx, ctx->materials, f.mats)) ||
+	    (rc = upload_vec(ctx, ctx->lights, f.lights)))
+		return rc;
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // the staging vectors die with this call
+	ctx->root_ref = f.root;
+	ctx->stack_depth = f.depth;
+	ctx->n_prims = desc->n_prims;
+	ctx->n_lights = desc->n_lights;
+	ctx->have_scene = true;
+	return RTA_OK;
+}
+
+int64_t rta_shard_pixels(int32_t width, int32_t height, int32_t shard_index, int32_t shard_count, int32_t *out)
+{
+	if (width <= 0 || height <= 0 || shard_count <= 0 || shard_index < 0 || shard_index >= shard_count)
+		return RTA_E_INVALID;
+	std::vector<int32_t> px;
+	shard_pixels(width, height, shard_index, shard_count, px);
+	if (out)
+		memcpy(out, px.data(), px.size() * sizeof(int32_t));
+	return (int64_t)px.size();
+}
+
+// ------------------------------------------------------------------ ray batches
+
+int rta_trace_closest(rta_context *ctx, const float *rays, int64_t n, rta_hit *hits, int mem)
+{
+	if (!ctx)
+		return RTA_E_INVALID;
+	if (!ctx->have_scene)
+		return ctx->fail(RTA_E_NO_SCENE, "no scene uploaded");
+	if (n < 0 || (n > 0 && (!rays || !hits)))
+		return ctx->fail(RTA_E_INVALID, "bad ray batch arguments");
+	if (n == 0)
+		return RTA_OK;
+	if ((uint64_t)n > (uint64_t)0x7fffffff * 256)
+		return ctx->fail(RTA_E_LIMIT, "ray batch too large for one launch");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	const float *d_rays = rays;
+	rta_hit *d_hits = hits;
+	if (mem == RTA_MEM_HOST) {
+		HIP_TRY(ctx, ctx->io_a.reserve((size_t)n * 24));
+		HIP_TRY(ctx, ctx->io_b.reserve((size_t)n * sizeof(rta_hit)));
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->io_a.ptr, rays, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+		d_rays = ctx->io_a.as<const float>();
+		d_hits = ctx->io_b.as<rta_hit>();
+	}
+	launch_batch_closest(ctx->stream, tree_of(ctx), d_rays, (uint64_t)n, d_hits, ctx->stack_depth, nullptr);
+	HIP_TRY(ctx, hipGetLastError());
+	if (mem == RTA_MEM_HOST)
+		HIP_TRY(ctx, hipMemcpyAsync(hits, d_hits, (size_t)n * sizeof(rta_hit), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return RTA_OK;
+}
+
+int rta_trace_occluded(rta_context *ctx, const float *rays, const float *tmax, int64_t n, uint8_t *out, int mem)
+{
+	if (!ctx)
+		return RTA_E_INVALID;
+	if (!ctx->have_scene)
+		return ctx->fail(RTA_E_NO_SCENE, "no scene uploaded");
+	if (n < 0 || (n > 0 && (!rays || !tmax || !out)))
+		return ctx->fail(RTA_E_INVALID, "bad ray batch arguments");
+	if (n == 0)
+		return RTA_OK;
+	if ((uint64_t)n > (uint64_t)0x7fffffff * 256)
+		return ctx->fail(RTA_E_LIMIT, "ray batch too large for one launch");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	const float *d_rays = rays, *d_tmax = tmax;
+	uint8_t *d_out = out;
+	if (mem == RTA_MEM_HOST) {
+		HIP_TRY(ctx, ctx->io_a.reserve((size_t)n * 24));
+		HIP_TRY(ctx, ctx->io_b.reserve((size_t)n * 4));
+		HIP_TRY(ctx, ctx->io_c.reserve((size_t)n));
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->io_a.ptr, rays, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->io_b.ptr, tmax, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+		d_rays = ctx->io_a.as<const float>();
+		d_tmax = ctx->io_b.as<const float>();
+		d_out = ctx->io_c.as<uint8_t>();
+	}
+	launch_batch_occluded(ctx->stream, tree_of(ctx), d_rays, d_tmax, (uint64_t)n, d_out, ctx->stack_depth);
+	HIP_TRY(ctx, hipGetLastError());
+	if (mem == RTA_MEM_HOST)
+		HIP_TRY(ctx, hipMemcpyAsync(out, d_out, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return RTA_OK;
+}
+
+int rta_debug_arith(rta_context *ctx, int op, const float *x, const float *y, float *out, int64_t n)
+{
+	if (!ctx)
+		return RTA_E_INVALID;
+	if (n <= 0 || !x || !y || !out)
+		return ctx->fail(RTA_E_INVALID, "bad arguments");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	HIP_TRY(ctx, ctx->io_a.reserve((size_t)n * 4));
+	HIP_TRY(ctx, ctx->io_b.reserve((size_t)n * 4));
+	HIP_TRY(ctx, ctx->io_c.reserve((size_t)n * 4));
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->io_a.ptr, x, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->io_b.ptr, y, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+	launch_arith(ctx->stream, op, ctx->io_a.as<const float>(), ctx->io_b.as<const float>(), ctx->io_c.as<float>(),
+	             (uint64_t)n);
+	HIP_TRY(ctx, hipGetLastError());
+	HIP_TRY(ctx, hipMemcpyAsync(out, ctx->io_c.ptr, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return RTA_OK;
+}
+
+// ------------------------------------------------------------------ render
+
+int rta_resolve(rta_context *ctx, const float *accum, int32_t width, int32_t height, int32_t samples, float exposure,
+                uint8_t *bgr, int mem)
+{
+	if (!ctx)
+		return RTA_E_INVALID;
+	if (!accum || !bgr || width <= 0 || height <= 0)
+		return ctx->fail(RTA_E_INVALID, "bad resolve arguments");
+	const size_t n = (size_t)width * height;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	const float *d_acc = accum;
+	uint8_t *d_bgr = bgr;
+	if (mem == RTA_MEM_HOST) {
+		HIP_TRY(ctx, ctx->io_a.reserve(n * 12));
+		HIP_TRY(ctx, ctx->io_c.reserve(n * 3));
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->io_a.ptr, accum, n * 12, hipMemcpyHostToDevice, ctx->stream));
+		d_acc = ctx->io_a.as<const float>();
+		d_bgr = ctx->io_c.as<uint8_t>();
+	}
+	launch_resolve(ctx->stream, d_acc, nullptr, (uint32_t)n, (float)samples, exposure, d_bgr);
+	HIP_TRY(ctx, hipGetLastError());
+	if (mem == RTA_MEM_HOST)
+		HIP_TRY(ctx, hipMemcpyAsync(bgr, d_bgr, n * 3, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return RTA_OK;
+}
+
+int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_params *p, float *accum, uint8_t *bgr,
+               rta_stats *stats)
+{
+	if (!ctx)
+		return RTA_E_INVALID;
+	if (!ctx->have_scene)
+		return ctx->fail(RTA_E_NO_SCENE, "no scene uploaded");
+	if (!camera || !p)
+		return ctx->fail(RTA_E_INVALID, "null camera or parameters");
+	if (p->width <= 0 || p->height <= 0 || p->samples <= 0)
+		return ctx->fail(RTA_E_INVALID, "width, height and samples must be positive");
+	const int32_t n_shards = p->shard_count <= 0 ? 1 : p->shard_count;
+	if (p->shard_index < 0 || p->shard_index >= n_shards)
+		return ctx->fail(RTA_E_INVALID, "shard_index out of range");
+	if ((int64_t)p->width * p->height > 0x7fffffff / 3)
+		return ctx->fail(RTA_E_LIMIT, "frame too large");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+	std::vector<int32_t> px;
+	shard_pixels(p->width, p->height, p->shard_index, n_shards, px);
+	const uint32_t n_owned = (uint32_t)px.size();
+	const uint32_t spp = (uint32_t)p->samples;
+	const uint32_t sps = p->samples_per_stream <= 0 ? spp : std::min((uint32_t)p->samples_per_stream, spp);
+	const uint32_t n_blocks = (spp + sps - 1) / sps;
+	const uint64_t items64 = (uint64_t)n_owned * n_blocks;
+	const size_t frame_px = (size_t)p->width * p->height;
+	rta_stats st;
+	memset(&st, 0, sizeof st);
+
+	uint32_t n_slots = p->slots > 0 ? (uint32_t)p->slots : (1u << 21);
+	n_slots = (uint32_t)std::min<uint64_t>(n_slots, std::max<uint64_t>(items64, 1));
+	n_slots = (n_slots + 63) / 64 * 64;
+	if (items64 + n_slots >= 0xffffffffull)
+		return ctx->fail(RTA_E_LIMIT, "pixels x sample blocks exceeds 2^32; raise samples_per_stream");
+	const uint32_t n_items = (uint32_t)items64;
+
+	// workspace (grow-only, reused across calls)
+	const size_t S = n_slots;
+	HIP_TRY(ctx, ctx->ray0.reserve(S * 16));
+	HIP_TRY(ctx, ctx->ray1.reserve(S * 16));
+	HIP_TRY(ctx, ctx->hit.reserve(S * 16));
+	HIP_TRY(ctx, ctx->thr.reserve(S * 16));
+	HIP_TRY(ctx, ctx->col.reserve(S * 16));
+	HIP_TRY(ctx, ctx->acc.reserve(S * 16));
+	HIP_TRY(ctx, ctx->q_ray0.reserve(S * 4));
+	HIP_TRY(ctx, ctx->q_ray1.reserve(S * 4));
+	HIP_TRY(ctx, ctx->q_regen.reserve(S * 4));
+	if (ctx->n_lights > 0)
+		HIP_TRY(ctx, ctx->shadow.reserve(S * 48));
+	HIP_TRY(ctx, ctx->partial.reserve(std::max<size_t>(n_items, 1) * 16));
+	HIP_TRY(ctx, ctx->pixels.reserve(std::max<size_t>(n_owned, 1) * 4));
+
+	const bool to_device = p->out_mem == RTA_MEM_DEVICE;
+	float *d_frame = nullptr;
+	uint8_t *d_bgr = nullptr;
+	if (to_device) {
+		d_frame = accum;
+		d_bgr = bgr;
+		if (!d_frame && bgr) {
+			HIP_TRY(ctx, ctx->frame.reserve(frame_px * 12));
+			d_frame = ctx->frame.as<float>();
+		}
+	} else {
+		HIP_TRY(ctx, ctx->frame.reserve(frame_px * 12));
+		d_frame = ctx->frame.as<float>();
+		if (bgr) {
+			HIP_TRY(ctx, ctx->bgr.reserve(frame_px * 3));
+			d_bgr = ctx->bgr.as<uint8_t>();
+		}
+	}
+
+	RenderArgs a;
+	memset(&a, 0, sizeof a);
+	a.tree = tree_of(ctx);
+	a.shade_prims = ctx->shade_prims.as<const float4>();
+	a.materials = ctx->materials.as<const float4>();
+	a.lights = ctx->lights.as<const float4>();
+	a.n_lights = ctx->n_lights;
+	a.ray0 = ctx->ray0.as<float4>();
+	a.ray1 = ctx->ray1.as<float4>();
+	a.hit = ctx->hit.as<float4>();
+	a.thr = ctx->thr.as<float4>();
+	a.col = ctx->col.as<float4>();
+	a.acc = ctx->acc.as<float4>();
+	a.q_ray[0] = ctx->q_ray0.as<uint32_t>();
+	a.q_ray[1] = ctx->q_ray1.as<uint32_t>();
+	a.q_regen = ctx->q_regen.as<uint32_t>();
+	a.shadow = ctx->shadow.as<float4>();
+	a.cnt = ctx->counters.as<Counters>();
+	a.partial = ctx->partial.as<float4>();
+	a.pixels = ctx->pixels.as<const int32_t>();
+	a.n_owned = n_owned;
+	a.n_items = n_items;
+	a.spp = spp;
+	a.sps = sps;
+	a.width = (uint32_t)p->width;
+	a.seed = p->seed;
+	a.max_bounces = p->max_bounces > 0 ? p->max_bounces : 10;
+	memcpy(a.sky, p->sky, sizeof a.sky);
+	a.cam = *camera;
+
+	const bool time_kernels = (p->flags & RTA_RENDER_TIME_KERNELS) != 0;
+	const bool count_work = (p->flags & RTA_RENDER_COUNT_WORK) != 0;
+	const bool lights = ctx->n_lights > 0;
+	hipStream_t s = ctx->stream;
+
+	hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+	HIP_TRY(ctx, hipEventCreate(&ev_begin));
+	HIP_TRY(ctx, hipEventCreate(&ev_end));
+	std::vector<hipEvent_t> ev_pool;        // begin/end pairs around timed launches
+	std::vector<int> ev_kind;               // 0 intersect, 1 shadow
+	auto cleanup = [&]() {
+		(void)hipEventDestroy(ev_begin);
+		(void)hipEventDestroy(ev_end);
+		for (hipEvent_t e : ev_pool)
+			(void)hipEventDestroy(e);
+	};
+#define HIP_TRY_R(call)                                      \
+	do {                                                     \
+		hipError_t e__ = (call);                             \
+		if (e__ != hipSuccess) {                             \
+			cleanup();                                       \
+			return ctx->hip_fail(e__, #call);                \
+		}                                                    \
+	} while (0)
+
+	if (n_owned)
+		HIP_TRY_R(hipMemcpyAsync(ctx->pixels.ptr, px.data(), (size_t)n_owned * 4, hipMemcpyHostToDevice, s));
+	Counters init;
+	memset(&init, 0, sizeof init);
+	init.n_regen = n_slots;
+	init.live = n_slots;
+	*ctx->host_counters = init;
+	HIP_TRY_R(hipMemcpyAsync(ctx->counters.ptr, ctx->host_counters, sizeof(Counters), hipMemcpyHostToDevice, s));
+	HIP_TRY_R(hipStreamSynchronize(s));       // host_counters is reused for read-back below
+
+	HIP_TRY_R(hipEventRecord(ev_begin, s));
+	launch_init_slots(s, a, n_slots);
+
+	// The wavefront loop.  Queue lengths live on the device; the host only
+	// learns them every `poll` steps, to shrink the launch bound and to notice
+	// the end.  `bound` is an upper limit on every queue's length.
+	uint32_t bound = n_slots;
+	const int poll = 16;
+	int cur = 0;
+	uint64_t steps = 0;
+	bool done = n_items == 0;
+	while (!done) {
+		for (int k = 0; k < poll; k++) {
+			launch_generate(s, a, cur, bound);
+			if (time_kernels) {
+				hipEvent_t e0, e1;
+				HIP_TRY_R(hipEventCreate(&e0));
+				ev_pool.push_back(e0);
+				HIP_TRY_R(hipEventCreate(&e1));
+				ev_pool.push_back(e1);
+				ev_kind.push_back(0);
+				HIP_TRY_R(hipEventRecord(e0, s));
+				launch_intersect(s, a, cur, bound, ctx->stack_depth, count_work);
+				HIP_TRY_R(hipEventRecord(e1, s));
+			} else {
+				launch_intersect(s, a, cur, bound, ctx->stack_depth, count_work);
+			}
+			launch_shade(s, a, cur, bound);
+			if (lights) {
+				if (time_kernels) {
+					hipEvent_t e0, e1;
+					HIP_TRY_R(hipEventCreate(&e0));
+					ev_pool.push_back(e0);
+					HIP_TRY_R(hipEventCreate(&e1));
+					ev_pool.push_back(e1);
+					ev_kind.push_back(1);
+					HIP_TRY_R(hipEventRecord(e0, s));
+					launch_shadow(s, a, bound, ctx->stack_depth, count_work);
+					HIP_TRY_R(hipEventRecord(e1, s));
+				} else {
+					launch_shadow(s, a, bound, ctx->stack_depth, count_work);
+				}
+			}
+			cur ^= 1;
+			steps++;
+		}
+		HIP_TRY_R(hipGetLastError());
+		HIP_TRY_R(hipMemcpyAsync(ctx->host_counters, ctx->counters.ptr, sizeof(Counters), hipMemcpyDeviceToHost, s));
+		HIP_TRY_R(hipStreamSynchronize(s));
+		const uint32_t live = ctx->host_counters->live;
+		if (live == 0)
+			done = true;
+		else
+			bound = std::min(bound, (live + 63) / 64 * 64);
+	}
+
+	const uint32_t blocks = n_blocks;
+	if (d_frame && n_owned) {
+		launch_sum_blocks(s, a.partial, a.pixels, n_owned, blocks, d_frame);
+		if (d_bgr)
+			launch_resolve(s, d_frame, a.pixels, n_owned, (float)spp, p->exposure, d_bgr);
+	}
+	HIP_TRY_R(hipEventRecord(ev_end, s));
+	HIP_TRY_R(hipGetLastError());
+	HIP_TRY_R(hipMemcpyAsync(ctx->host_counters, ctx->counters.ptr, sizeof(Counters), hipMemcpyDeviceToHost, s));
+	HIP_TRY_R(hipStreamSynchronize(s));
+
+	if (!to_device && n_owned) {
+		// copy out only what this shard owns, row by row of its tiles
+		std::vector<float> h_frame;
+		std::vector<uint8_t> h_bgr;
+		if (accum) {
+			h_frame.resize(frame_px * 3);
+			HIP_TRY_R(hipMemcpy(h_frame.data(), d_frame, frame_px * 12, hipMemcpyDeviceToHost));
+			for (int32_t q : px)
+				memcpy(accum + (size_t)q * 3, h_frame.data() + (size_t)q * 3, 12);
+		}
+		if (bgr) {
+			h_bgr.resize(frame_px * 3);
+			HIP_TRY_R(hipMemcpy(h_bgr.data(), d_bgr, frame_px * 3, hipMemcpyDeviceToHost));
+			for (int32_t q : px)
+				memcpy(bgr + (size_t)q * 3, h_bgr.data() + (size_t)q * 3, 3);
+		}
+	}
+
+	float ms = 0;
+	HIP_TRY_R(hipEventElapsedTime(&ms, ev_begin, ev_end));
+	st.gpu_ms = ms;
+	for (size_t k = 0; k < ev_kind.size(); k++) {
+		float t = 0;
+		HIP_TRY_R(hipEventElapsedTime(&t, ev_pool[2 * k], ev_pool[2 * k + 1]));
+		if (ev_kind[k] == 0) {
+			st.intersect_ms += t;
+			st.intersect_launches++;
+		} else {
+			st.shadow_ms += t;
+			st.shadow_launches++;
+		}
+	}
+	const Counters &c = *ctx->host_counters;
+	st.samples = (uint64_t)n_owned * spp;
+	st.rays = c.rays;
+	st.shadow_rays = c.shadow_rays;
+	st.steps = steps;
+	st.inner_visits = c.inner;
+	st.tri_tests = c.tri;
+	st.sph_tests = c.sph;
+	if (stats)
+		*stats = st;
+	cleanup();
+#undef HIP_TRY_R
+	return RTA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,559 @@
+// HIP kernels of the wavefront path tracer (gfx950, wave64) and their
+// launchers.  The reference's per-pixel loop (src/main.cpp:657-714) becomes
+// four kernels per wavefront step that talk through compacted queues of path
+// slots:
+//
+//   generate   retire finished samples into their block sum, hand out the next
+//              sample block, draw the camera ray (src/main.cpp:663-687)
+//   intersect  closest hit (src/main.cpp:332-422)
+//   shade      one bounce of RayTrace (src/main.cpp:507-589): emission, light
+//              sampling, BSDF sampling, Russian roulette
+//   shadow     occlusion query for the sampled light (src/main.cpp:424-478) and
+//              the deferred radiance add
+//
+// followed once by block-sum accumulation and the tone-mapping resolve
+// (src/main.cpp:692-706).
+//
+// A path slot owns one (pixel, sample block) work item at a time and carries
+// its xorshift32 state from sample to sample, so a block's samples are drawn
+// and summed strictly in order; blocks are handed out through one atomic
+// counter.  Results therefore depend only on (seed, pixel, block), never on the
+// schedule.
+
+#include "kernels.hpp"
+
+#include "shading.hpp"
+#include "traverse.hpp"
+
+namespace rta {
+
+namespace {
+
+constexpr uint32_t kNoItem = 0xffffffffu;
+
+RTA_DEV float4 f4(V3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
+RTA_DEV float4 f4u(V3 v, uint32_t w) { return make_float4(v.x, v.y, v.z, __uint_as_float(w)); }
+RTA_DEV V3 xyz(float4 q) { return mk(q.x, q.y, q.z); }
+
+// Wave-level queue append: one atomic per wave64.  Must be reached by every
+// lane of the wave (pass pred = false for lanes with nothing to add).
+RTA_DEV uint32_t queue_push(bool pred, uint32_t *counter)
+{
+	const unsigned long long mask = __ballot(pred);
+	if (mask == 0)
+		return 0;
+	const uint32_t before =
+	    __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+	const int leader = __ffsll((long long)mask) - 1;
+	uint32_t base = 0;
+	if ((int)(threadIdx.x & 63) == leader)
+		base = atomicAdd(counter, (uint32_t)__popcll(mask));
+	base = __shfl(base, leader);
+	return base + before;
+}
+
+RTA_DEV void count_flush(Counters *cnt, const WorkCount &wc)
+{
+	if (wc.inner) atomicAdd(&cnt->inner, (unsigned long long)wc.inner);
+	if (wc.tri) atomicAdd(&cnt->tri, (unsigned long long)wc.tri);
+	if (wc.sph) atomicAdd(&cnt->sph, (unsigned long long)wc.sph);
+}
+
+// ------------------------------------------------------------------ generate
+
+__global__ __launch_bounds__(kBlock) void k_generate(const RenderArgs a, const int cur)
+{
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	const uint32_t n = a.cnt->n_regen;
+	bool push = false;
+	uint32_t slot = 0;
+	if (i < n) {
+		slot = a.q_regen[i];
+		float4 A = a.acc[slot];
+		float4 C = a.col[slot];
+		uint32_t rng = __float_as_uint(a.thr[slot].w);
+		uint32_t item = __float_as_uint(A.w);
+		uint32_t done = __float_as_uint(C.w);
+		if (item != kNoItem) {
+			// the finished sample joins its block sum (src/main.cpp:689)
+			A.x += C.x;
+			A.y += C.y;
+			A.z += C.z;
+			done++;
+			const uint32_t block = item / a.n_owned;
+			const uint32_t first = block * a.sps;
+			const uint32_t len = a.spp - first < a.sps ? a.spp - first : a.sps;
+			if (done >= len) {
+				a.partial[item] = make_float4(A.x, A.y, A.z, 0.f);
+				item = kNoItem;
+			}
+		}
+		if (item == kNoItem) {
+			const uint32_t got = atomicAdd(&a.cnt->next_item, 1u);
+			if (got < a.n_items) {
+				item = got;
+				const uint32_t block = item / a.n_owned;
+				const uint32_t pixel = (uint32_t)a.pixels[item - block * a.n_owned];
+				rng = stream_seed(a.seed, pixel, block);
+				A.x = A.y = A.z = 0.f;
+				done = 0;
+			} else {
+				atomicSub(&a.cnt->live, 1u);
+			}
+		}
+		A.w = __uint_as_float(item);
+		a.acc[slot] = A;
+		if (item != kNoItem) {
+			const uint32_t block = item / a.n_owned;
+			const uint32_t pixel = (uint32_t)a.pixels[item - block * a.n_owned];
+			const uint32_t pu = pixel % a.width, pv = pixel / a.width;
+			const V3 cam_o = mk(a.cam.origin[0], a.cam.origin[1], a.cam.origin[2]);
+			V3 origin = cam_o;
+			if (a.cam.defocus_angle > 0) {
+				// src/main.cpp:105-113,665-669; the accept test is x*y < 1 as written there
+				float lx, ly;
+				for (;;) {
+					lx = rng_float(rng) * 2 - 1;
+					ly = rng_float(rng) * 2 - 1;
+					if (lx * ly < 1)
+						break;
+				}
+				const V3 lu = mk(a.cam.lens_u[0], a.cam.lens_u[1], a.cam.lens_u[2]);
+				const V3 lv = mk(a.cam.lens_v[0], a.cam.lens_v[1], a.cam.lens_v[2]);
+				origin = (cam_o + lu * lx) + lv * ly;
+			}
+			// Gaussian pixel filter by Box-Muller, sigma = 0.5 px (src/main.cpp:674-683)
+			float u1;
+			do {
+				u1 = rng_float(rng);
+			} while (u1 == 0);
+			const float u2 = rng_float(rng);
+			const float radius = .5f * __builtin_sqrtf(-2 * pm_logf(u1));
+			const float ju = radius * pm_cosf(2 * kPiF * u2);
+			const float jv = radius * pm_sinf(2 * kPiF * u2);
+			const V3 ul = mk(a.cam.upper_left[0], a.cam.upper_left[1], a.cam.upper_left[2]);
+			const V3 du = mk(a.cam.du[0], a.cam.du[1], a.cam.du[2]);
+			const V3 dv = mk(a.cam.dv[0], a.cam.dv[1], a.cam.dv[2]);
+			const V3 target = (ul + du * ((float)pu + .5f + ju)) + dv * ((float)pv + .5f + jv);
+			const V3 dir = unit(target - origin);
+			a.ray0[slot] = make_float4(origin.x, origin.y, origin.z, dir.x);
+			a.ray1[slot] = make_float4(dir.y, dir.z, 1.f, __uint_as_float(0u));     // bsdf_pdf = 1, bounce 0
+			a.thr[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(rng));
+			a.col[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(done));
+			push = true;
+		}
+	}
+	const uint32_t at = queue_push(push, &a.cnt->n_ray[cur]);
+	if (push)
+		a.q_ray[cur][at] = slot;
+}
+
+// ------------------------------------------------------------------ intersect
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_intersect(const RenderArgs a, const int cur, const int depth)
+{
+	extern __shared__ uint32_t lds_stack[];
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	const uint32_t n = a.cnt->n_ray[cur];
+	if (i == 0) {
+		// queues that nobody reads or appends to during this launch
+		a.cnt->n_regen = 0;
+		a.cnt->n_ray[cur ^ 1] = 0;
+		a.cnt->n_shadow = 0;
+		a.cnt->rays += n;
+	}
+	WorkCount wc = {0, 0, 0};
+	if (i < n) {
+		const uint32_t slot = a.q_ray[cur][i];
+		const float4 r0 = a.ray0[slot], r1 = a.ray1[slot];
+		Ray ray = {mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y)};
+		HitRec h;
+		traverse_dyn<false, COUNT>(a.tree, ray, FLT_MAX, lds_stack + threadIdx.x, depth, h, wc);
+		a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
+	}
+	if (COUNT)
+		count_flush(a.cnt, wc);
+}
+
+// ------------------------------------------------------------------ shade
+
+__global__ __launch_bounds__(kBlock) void k_shade(const RenderArgs a, const int cur)
+{
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	const uint32_t n = a.cnt->n_ray[cur];
+	bool alive = false, ended = false, want_shadow = false;
+	uint32_t slot = 0;
+	V3 sh_o = mk(0, 0, 0), sh_d = mk(0, 0, 0), sh_c = mk(0, 0, 0);
+	float sh_dist = 0;
+
+	if (i < n) {
+		slot = a.q_ray[cur][i];
+		const float4 r0 = a.ray0[slot], r1 = a.ray1[slot];
+		const float4 H = a.hit[slot];
+		float4 T = a.thr[slot];
+		float4 C = a.col[slot];
+		const Ray ray = {mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y)};
+		const float prev_pdf = r1.z;
+		const uint32_t bounce = __float_as_uint(r1.w);
+		uint32_t rng = __float_as_uint(T.w);
+		V3 thr = xyz(T), color = xyz(C);
+		const int32_t prim = __float_as_int(H.x);
+
+		if (prim < 0) {
+			// src/main.cpp:511-514
+			color = color + thr * mk(a.sky[0], a.sky[1], a.sky[2]);
+			ended = true;
+		} else {
+			const float t = H.y, bu = H.z, bv = H.w;
+			const float4 s0 = a.shade_prims[3 * (size_t)prim];
+			const float4 s1 = a.shade_prims[3 * (size_t)prim + 1];
+			const float4 s2 = a.shade_prims[3 * (size_t)prim + 2];
+			const int32_t mat_id = __float_as_int(s0.w), light_id = __float_as_int(s1.w);
+			const bool is_sphere = __float_as_int(s2.w) == RTA_PRIM_SPHERE;
+
+			// src/main.cpp:353-354,365-368
+			const V3 point = ray.o + ray.d * t;
+			V3 normal;
+			if (is_sphere) {
+				const float4 g0 = a.tree.prims[3 * (size_t)prim], g1 = a.tree.prims[3 * (size_t)prim + 1];
+				normal = (point - xyz(g0)) / g1.x;
+			} else {
+				const float bw = 1 - bu - bv;
+				normal = unit((xyz(s0) * bu + xyz(s1) * bv) + xyz(s2) * bw);
+			}
+			bool front = true;
+			if (dot(ray.d, normal) > 0) {
+				normal = -normal;
+				front = false;
+			}
+			const float4 m0 = a.materials[2 * (size_t)mat_id], m1 = a.materials[2 * (size_t)mat_id + 1];
+			const Material mat = {xyz(m0), m0.w, m1.x, m1.y};
+
+			const Frame fr = frame_from_normal(normal);
+			const V3 v = to_local(fr, -ray.d);
+
+			// emitted light, MIS-weighted after the first bounce (src/main.cpp:531-543)
+			if (front && light_id >= 0) {
+				const float4 *L = a.lights + 7 * (size_t)light_id;
+				const V3 le = xyz(L[0]);
+				if (bounce == 0 || a.n_lights == 0) {
+					color = color + thr * le;
+				} else {
+					const float pmf = 1.f / (float)a.n_lights;
+					const float lpdf = pmf * triangle_pdf(xyz(L[1]), xyz(L[2]), xyz(L[3]), ray.o, point, normal);
+					const float w = power_heuristic(prev_pdf, lpdf);
+					color = color + (thr * le) * w;
+				}
+			}
+
+			// next-event estimation on one uniformly chosen triangle light
+			// (src/main.cpp:545-571); the visibility test is deferred to k_shadow
+			if (a.n_lights > 0) {
+				const uint32_t li = rng_next(rng) % (uint32_t)a.n_lights;
+				const float4 *L = a.lights + 7 * (size_t)li;
+				// src/main.cpp:115-131
+				const float r1u = rng_float(rng);
+				const float r2u = rng_float(rng);
+				float b0, b1;
+				if (r1u < r2u) {
+					b0 = r1u / 2;
+					b1 = r2u - b0;
+				} else {
+					b1 = r2u / 2;
+					b0 = r1u - b1;
+				}
+				const float b2 = 1 - b0 - b1;
+				const V3 lp = (xyz(L[1]) * b0 + xyz(L[2]) * b1) + xyz(L[3]) * b2;
+				const V3 ln = unit((xyz(L[4]) * b0 + xyz(L[5]) * b1) + xyz(L[6]) * b2);
+				V3 ld = lp - point;
+				const float dist = norm(ld);
+				ld = ld / dist;
+				const V3 l = to_local(fr, ld);
+				if (dot(ld, ln) < 0) {
+					const float pmf = 1.f / (float)a.n_lights;
+					const float lpdf = pmf * triangle_pdf(xyz(L[1]), xyz(L[2]), xyz(L[3]), point, lp, ln);
+					const float bpdf = bsdf_pdf(v, l, mat);
+					const float w = power_heuristic(lpdf, bpdf);
+					const V3 f = bsdf_eval(v, l, mat);
+					sh_c = (((thr * xyz(L[0])) * f) * w) / lpdf;
+					sh_o = point;
+					sh_d = ld;
+					sh_dist = dist - .0001f;
+					want_shadow = true;
+				}
+			}
+
+			// src/main.cpp:573-588
+			const BsdfSample s = sample_bsdf(v, mat, rng);
+			thr = thr * (s.f / s.pdf);
+			bool stop = false;
+			if (bounce > 3) {
+				const float p = greater(thr.x, greater(thr.y, thr.z));
+				if (rng_float(rng) < (1 - p))
+					stop = true;
+				else
+					thr = thr / p;
+			}
+			if (!stop && bounce + 1 < (uint32_t)a.max_bounces) {
+				const V3 nd = to_world(fr, s.l);
+				a.ray0[slot] = make_float4(point.x, point.y, point.z, nd.x);
+				a.ray1[slot] = make_float4(nd.y, nd.z, s.pdf, __uint_as_float(bounce + 1));
+				alive = true;
+			} else {
+				ended = true;
+			}
+		}
+		a.thr[slot] = f4u(thr, rng);
+		a.col[slot] = make_float4(color.x, color.y, color.z, C.w);
+	}
+
+	const uint32_t at_ray = queue_push(alive, &a.cnt->n_ray[cur ^ 1]);
+	if (alive)
+		a.q_ray[cur ^ 1][at_ray] = slot;
+	const uint32_t at_regen = queue_push(ended, &a.cnt->n_regen);
+	if (ended)
+		a.q_regen[at_regen] = slot;
+	if (a.n_lights > 0) {
+		const uint32_t at_sh = queue_push(want_shadow, &a.cnt->n_shadow);
+		if (want_shadow) {
+			float4 *e = a.shadow + 3 * (size_t)at_sh;
+			e[0] = f4(sh_o, sh_dist);
+			e[1] = f4u(sh_d, slot);
+			e[2] = f4(sh_c, 0.f);
+		}
+	}
+}
+
+// ------------------------------------------------------------------ shadow
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_shadow(const RenderArgs a, const int depth)
+{
+	extern __shared__ uint32_t lds_stack[];
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	const uint32_t n = a.cnt->n_shadow;
+	if (i == 0)
+		a.cnt->shadow_rays += n;
+	WorkCount wc = {0, 0, 0};
+	if (i < n) {
+		const float4 *e = a.shadow + 3 * (size_t)i;
+		const float4 e0 = e[0], e1 = e[1], e2 = e[2];
+		Ray ray = {xyz(e0), xyz(e1)};
+		HitRec h;
+		traverse_dyn<true, COUNT>(a.tree, ray, e0.w, lds_stack + threadIdx.x, depth, h, wc);
+		if (h.prim < 0) {
+			// src/main.cpp:569: the light's contribution joins the path radiance
+			const uint32_t slot = __float_as_uint(e1.w);
+			float4 C = a.col[slot];
+			C.x += e2.x;
+			C.y += e2.y;
+			C.z += e2.z;
+			a.col[slot] = C;
+		}
+	}
+	if (COUNT)
+		count_flush(a.cnt, wc);
+}
+
+// ------------------------------------------------------------------ finish
+
+// Pixel sum = block sums added in block order from zero.
+__global__ __launch_bounds__(kBlock) void k_sum_blocks(const float4 *partial, const int32_t *pixels, uint32_t n_owned,
+                                                       uint32_t n_blocks, float *frame)
+{
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= n_owned)
+		return;
+	float x = 0, y = 0, z = 0;
+	for (uint32_t b = 0; b < n_blocks; b++) {
+		const float4 p = partial[(size_t)b * n_owned + i];
+		x += p.x;
+		y += p.y;
+		z += p.z;
+	}
+	float *dst = frame + (size_t)pixels[i] * 3;
+	dst[0] = x;
+	dst[1] = y;
+	dst[2] = z;
+}
+
+// src/main.cpp:692-706: mean, blue/green error markers, tone map, truncation,
+// B,G,R byte order.
+RTA_DEV uint8_t to_byte(float x)
+{
+	// float -> int as the x86 cvttss2si the reference compiles to: NaN and
+	// out-of-range become INT_MIN, whose low byte is 0
+	int v;
+	if (!(x > -2147483648.f && x < 2147483648.f))
+		v = (int)0x80000000;
+	else
+		v = (int)x;
+	return (uint8_t)v;
+}
+
+__global__ __launch_bounds__(kBlock) void k_resolve(const float *frame, const int32_t *pixels, uint32_t n, float samples,
+                                                    float exposure, uint8_t *bgr)
+{
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= n)
+		return;
+	const size_t p = pixels ? (size_t)pixels[i] : (size_t)i;
+	V3 c = mk(frame[p * 3], frame[p * 3 + 1], frame[p * 3 + 2]) / samples;
+	if (c.x < 0 || c.y < 0 || c.z < 0)
+		c = mk(0, 0, 1);
+	if (c.x != c.x || c.y != c.y || c.z != c.z)
+		c = mk(0, 1, 0);
+	bgr[p * 3 + 2] = to_byte(255 * tonemap(c.x, exposure));
+	bgr[p * 3 + 1] = to_byte(255 * tonemap(c.y, exposure));
+	bgr[p * 3 + 0] = to_byte(255 * tonemap(c.z, exposure));
+}
+
+__global__ __launch_bounds__(kBlock) void k_init_slots(const RenderArgs a, uint32_t n_slots)
+{
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= n_slots)
+		return;
+	a.acc[i] = make_float4(0.f, 0.f, 0.f, __uint_as_float(kNoItem));
+	a.col[i] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
+	a.thr[i] = make_float4(1.f, 1.f, 1.f, __uint_as_float(1u));
+	a.q_regen[i] = i;
+}
+
+// ------------------------------------------------------------------ ray batches
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_batch_closest(const DeviceTree tree, const float *rays, uint64_t n,
+                                                          rta_hit *hits, const int depth, Counters *cnt)
+{
+	extern __shared__ uint32_t lds_stack[];
+	const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+	WorkCount wc = {0, 0, 0};
+	if (i < n) {
+		const float *r = rays + i * 6;
+		Ray ray = {mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5])};
+		HitRec h;
+		traverse_dyn<false, COUNT>(tree, ray, FLT_MAX, lds_stack + threadIdx.x, depth, h, wc);
+		rta_hit out;
+		out.prim = h.prim;
+		out.t = h.t;
+		out.u = h.u;
+		out.v = h.v;
+		hits[i] = out;
+	}
+	if (COUNT)
+		count_flush(cnt, wc);
+}
+
+__global__ __launch_bounds__(kBlock) void k_batch_occluded(const DeviceTree tree, const float *rays, const float *tmax,
+                                                           uint64_t n, uint8_t *out, const int depth)
+{
+	extern __shared__ uint32_t lds_stack[];
+	const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+	if (i >= n)
+		return;
+	const float *r = rays + i * 6;
+	Ray ray = {mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5])};
+	HitRec h;
+	WorkCount wc = {0, 0, 0};
+	traverse_dyn<true, false>(tree, ray, tmax[i], lds_stack + threadIdx.x, depth, h, wc);
+	out[i] = h.prim >= 0 ? 1 : 0;
+}
+
+__global__ __launch_bounds__(kBlock) void k_arith(int op, const float *x, const float *y, float *out, uint64_t n)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+	if (i >= n)
+		return;
+	const float a = x[i], b = y[i];
+	float r;
+	switch (op) {
+	case 0: r = a / b; break;
+	case 1: r = __builtin_sqrtf(a); break;
+	case 2: r = pm_sinf(a); break;
+	case 3: r = pm_cosf(a); break;
+	case 4: r = pm_logf(a); break;
+	case 5: r = pm_powf(a, b); break;
+	case 6: r = __builtin_fmaf(a, b, a); break;
+	default: r = a * b + a; break;
+	}
+	out[i] = r;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ launchers
+
+static inline unsigned blocks_for(uint64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+static inline size_t stack_bytes(int depth) { return (size_t)depth * kBlock * sizeof(uint32_t); }
+
+void launch_init_slots(hipStream_t s, const RenderArgs &a, uint32_t n_slots)
+{
+	hipLaunchKernelGGL(k_init_slots, dim3(blocks_for(n_slots)), dim3(kBlock), 0, s, a, n_slots);
+}
+
+void launch_generate(hipStream_t s, const RenderArgs &a, int cur, uint32_t bound)
+{
+	hipLaunchKernelGGL(k_generate, dim3(blocks_for(bound)), dim3(kBlock), 0, s, a, cur);
+}
+
+void launch_intersect(hipStream_t s, const RenderArgs &a, int cur, uint32_t bound, int depth, bool count)
+{
+	if (count)
+		hipLaunchKernelGGL(k_intersect<true>, dim3(blocks_for(bound)), dim3(kBlock), stack_bytes(depth), s, a, cur,
+		                   depth);
+	else
+		hipLaunchKernelGGL(k_intersect<false>, dim3(blocks_for(bound)), dim3(kBlock), stack_bytes(depth), s, a, cur,
+		                   depth);
+}
+
+void launch_shade(hipStream_t s, const RenderArgs &a, int cur, uint32_t bound)
+{
+	hipLaunchKernelGGL(k_shade, dim3(blocks_for(bound)), dim3(kBlock), 0, s, a, cur);
+}
+
+void launch_shadow(hipStream_t s, const RenderArgs &a, uint32_t bound, int depth, bool count)
+{
+	if (count)
+		hipLaunchKernelGGL(k_shadow<true>, dim3(blocks_for(bound)), dim3(kBlock), stack_bytes(depth), s, a, depth);
+	else
+		hipLaunchKernelGGL(k_shadow<false>, dim3(blocks_for(bound)), dim3(kBlock), stack_bytes(depth), s, a, depth);
+}
+
+void launch_sum_blocks(hipStream_t s, const float4 *partial, const int32_t *pixels, uint32_t n_owned, uint32_t n_blocks,
+                       float *frame)
+{
+	hipLaunchKernelGGL(k_sum_blocks, dim3(blocks_for(n_owned)), dim3(kBlock), 0, s, partial, pixels, n_owned, n_blocks,
+	                   frame);
+}
+
+void launch_resolve(hipStream_t s, const float *frame, const int32_t *pixels, uint32_t n, float samples, float exposure,
+                    uint8_t *bgr)
+{
+	hipLaunchKernelGGL(k_resolve, dim3(blocks_for(n)), dim3(kBlock), 0, s, frame, pixels, n, samples, exposure, bgr);
+}
+
+void launch_batch_closest(hipStream_t s, const TreeRef &tree, const float *rays, uint64_t n, rta_hit *hits, int depth,
+                          Counters *cnt)
+{
+	if (cnt)
+		hipLaunchKernelGGL(k_batch_closest<true>, dim3(blocks_for(n)), dim3(kBlock), stack_bytes(depth), s, tree, rays,
+		                   n, hits, depth, cnt);
+	else
+		hipLaunchKernelGGL(k_batch_closest<false>, dim3(blocks_for(n)), dim3(kBlock), stack_bytes(depth), s, tree, rays,
+		                   n, hits, depth, cnt);
+}
+
+void launch_batch_occluded(hipStream_t s, const TreeRef &tree, const float *rays, const float *tmax, uint64_t n,
+                           uint8_t *out, int depth)
+{
+	hipLaunchKernelGGL(k_batch_occluded, dim3(blocks_for(n)), dim3(kBlock), stack_bytes(depth), s, tree, rays, tmax, n,
+	                   out, depth);
+}
+
+void launch_arith(hipStream_t s, int op, const float *x, const float *y, float *out, uint64_t n)
+{
+	hipLaunchKernelGGL(k_arith, dim3(blocks_for(n)), dim3(kBlock), 0, s, op, x, y, out, n);
+}
+
+}  // namespace rta

@@ -1,0 +1,78 @@
+// Shared declarations between the HIP kernels (kernels.hip) and the host-side
+// context that drives them (context.cpp).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "raytracer_amd.h"
+
+namespace rta {
+
+// Device-resident queue lengths and statistics.  One instance per context.
+struct Counters {
+	uint32_t n_ray[2];       // closest-hit queue, double buffered
+	uint32_t n_regen;        // slots whose path ended this step
+	uint32_t n_shadow;       // pending occlusion queries
+	uint32_t next_item;      // next (pixel, block) work item to hand out
+	uint32_t live;           // slots that still own or may get a work item
+	uint32_t pad[2];
+	unsigned long long rays, shadow_rays;
+	unsigned long long inner, tri, sph;     // RTA_RENDER_COUNT_WORK only
+};
+
+struct TreeRef {
+	const float4 *pairs;
+	const float4 *prims;
+	uint32_t root;
+};
+
+// Everything a wavefront kernel needs, passed by value.
+struct RenderArgs {
+	TreeRef tree;
+	const float4 *shade_prims;     // 3 per primitive: (n0, material) (n1, light) (n2, type)
+	const float4 *materials;       // 2 per material: (color, alpha) (ior, metallic, -, -)
+	const float4 *lights;          // 7 per light: (color, prim) v0 v1 v2 n0 n1 n2
+	int32_t n_lights;
+
+	// per path slot
+	float4 *ray0;                  // origin xyz, direction x
+	float4 *ray1;                  // direction yz, pdf of the sampled direction, bounce
+	float4 *hit;                   // primitive, t, u, v
+	float4 *thr;                   // throughput rgb, rng state
+	float4 *col;                   // path radiance rgb, samples finished in the current block
+	float4 *acc;                   // block sum rgb, work item
+	// queues
+	uint32_t *q_ray[2];
+	uint32_t *q_regen;
+	float4 *shadow;                // 3 per entry: (origin, limit) (direction, slot) (radiance, -)
+	Counters *cnt;
+
+	float4 *partial;               // one block sum per work item
+	const int32_t *pixels;         // pixels owned by this shard
+	uint32_t n_owned, n_items;
+	uint32_t spp, sps;
+	uint32_t width;
+	uint32_t seed;
+	int32_t max_bounces;
+	float sky[3];
+	rta_camera cam;
+};
+
+void launch_init_slots(hipStream_t s, const RenderArgs &a, uint32_t n_slots);
+void launch_generate(hipStream_t s, const RenderArgs &a, int cur, uint32_t bound);
+void launch_intersect(hipStream_t s, const RenderArgs &a, int cur, uint32_t bound, int depth, bool count);
+void launch_shade(hipStream_t s, const RenderArgs &a, int cur, uint32_t bound);
+void launch_shadow(hipStream_t s, const RenderArgs &a, uint32_t bound, int depth, bool count);
+void launch_sum_blocks(hipStream_t s, const float4 *partial, const int32_t *pixels, uint32_t n_owned, uint32_t n_blocks,
+                       float *frame);
+void launch_resolve(hipStream_t s, const float *frame, const int32_t *pixels, uint32_t n, float samples, float exposure,
+                    uint8_t *bgr);
+void launch_batch_closest(hipStream_t s, const TreeRef &tree, const float *rays, uint64_t n, rta_hit *hits, int depth,
+                          Counters *cnt);
+void launch_batch_occluded(hipStream_t s, const TreeRef &tree, const float *rays, const float *tmax, uint64_t n,
+                           uint8_t *out, int depth);
+void launch_arith(hipStream_t s, int op, const float *x, const float *y, float *out, uint64_t n);
+
+}  // namespace rta

@@ -1,0 +1,216 @@
+// BVH traversal for gfx950: closest hit and any hit over the reference's own
+// tree (src/main.cpp:250-478), one ray per lane, traversal stack in LDS.
+//
+// Device layouts
+//   pair record, 64 B, one per inner node, holds BOTH children so that one
+//   visit is four 16-byte loads from one aligned 64-byte line:
+//     q0 = (L.min.x, L.min.y, L.min.z, L.max.x)
+//     q1 = (L.max.y, L.max.z, R.min.x, R.min.y)
+//     q2 = (R.min.z, R.max.x, R.max.y, R.max.z)
+//     q3 = (L.ref, R.ref, -, -) as integers
+//   a ref is either an inner node's pair index or kLeafBit | first primitive.
+//   Boxes are only ever read from the parent, so the stack holds bare refs.
+//
+//   primitive record, 48 B (three 16-byte loads), in BVH order:
+//     triangle  p0 = (v2.xyz, flags)  p1 = (v0-v2, 0)  p2 = (v1-v2, 0)
+//     sphere    p0 = (center.xyz, flags)  p1 = (radius, 0, 0, 0)
+//   flags bit 0: sphere; bit 1: last primitive of its leaf.  The edge vectors
+//   are the reference's own first two subtractions (src/main.cpp:252-253),
+//   done once at upload in fp32, so the test sees identical operands.
+#pragma once
+
+#include "device_math.hpp"
+#include "kernels.hpp"
+
+namespace rta {
+
+constexpr uint32_t kLeafBit = 0x80000000u;
+constexpr uint32_t kPrimSphere = 1u;
+constexpr uint32_t kPrimLast = 2u;
+constexpr int kBlock = 256;            // threads per workgroup of every traversal kernel
+
+using DeviceTree = TreeRef;    // pairs, prims, ref of the root node
+
+struct Ray {
+	V3 o, d;
+};
+
+struct HitRec {
+	int32_t prim;
+	float t, u, v;
+};
+
+struct WorkCount {
+	uint32_t inner, tri, sph;
+};
+
+// src/main.cpp:250-279 with e0/e1 precomputed
+RTA_DEV float test_triangle(V3 v2, V3 e0, V3 e1, const Ray &r, float &u_out, float &v_out)
+{
+	V3 pvec = cross(r.d, e1);
+	float det = dot(e0, pvec);
+	if (det > -.0001f && det < .0001f)
+		return FLT_MAX;
+	V3 tvec = r.o - v2;
+	float u = dot(tvec, pvec) / det;
+	if (u < 0 || u > 1)
+		return FLT_MAX;
+	V3 qvec = cross(tvec, e0);
+	float v = dot(r.d, qvec) / det;
+	if (v < 0 || u + v > 1)
+		return FLT_MAX;
+	float t = dot(e1, qvec) / det;
+	u_out = u;
+	v_out = v;
+	return t > .0001f ? t : FLT_MAX;
+}
+
+// src/main.cpp:281-301
+RTA_DEV float test_sphere(V3 center, float radius, const Ray &r)
+{
+	V3 oc = center - r.o;
+	float h = dot(r.d, oc);
+	float c = norm2(oc) - radius * radius;
+	float delta = h * h - c;
+	if (delta < .001f)
+		return FLT_MAX;
+	float sq = __builtin_sqrtf(delta);
+	float t = h - sq;
+	if (t < .001f) {
+		t = h + sq;
+		if (t < .001f)
+			return FLT_MAX;
+	}
+	return t;
+}
+
+// One axis of src/main.cpp:303-330: the direction's SIGN BIT picks the near
+// plane; both quotients are true divisions.
+RTA_DEV void slab(float lo, float hi, float o, float d, bool negative, float &tmin, float &tmax)
+{
+	float near_plane = negative ? hi : lo;
+	float far_plane = negative ? lo : hi;
+	float t1 = (near_plane - o) / d;
+	float t2 = (far_plane - o) / d;
+	tmin = greater(t1, tmin);
+	tmax = lesser(t2, tmax);
+}
+
+struct RaySigns {
+	bool x, y, z;
+};
+
+RTA_DEV RaySigns signs_of(const Ray &r)
+{
+	return RaySigns{(__float_as_uint(r.d.x) >> 31) != 0, (__float_as_uint(r.d.y) >> 31) != 0,
+	                (__float_as_uint(r.d.z) >> 31) != 0};
+}
+
+RTA_DEV float test_box(V3 lo, V3 hi, const Ray &r, RaySigns s, float max_t)
+{
+	float tmin = 0.f, tmax = FLT_MAX;
+	slab(lo.x, hi.x, r.o.x, r.d.x, s.x, tmin, tmax);
+	slab(lo.y, hi.y, r.o.y, r.d.y, s.y, tmin, tmax);
+	slab(lo.z, hi.z, r.o.z, r.d.z, s.z, tmin, tmax);
+	return (tmax >= tmin && tmin < max_t && tmax > 0) ? tmin : FLT_MAX;
+}
+
+// Traversal of src/main.cpp:332-422 (closest, ANY = false) and :424-478 (any
+// hit, ANY = true).  `stack` points at this lane's column of an LDS array laid
+// out [depth][kBlock], so consecutive lanes hit consecutive banks.  `depth` is
+// the number of entries the column has (the launch sizes dynamic LDS from it);
+// upload guarantees the tree never needs more.  For ANY, `limit` is the
+// distance bound and the result is hit.prim >= 0.
+template <bool ANY, bool COUNT>
+RTA_DEV void traverse_dyn(const DeviceTree &tree, const Ray &ray, float limit, uint32_t *stack, const int depth,
+                          HitRec &hit, WorkCount &work)
+{
+	const RaySigns sg = signs_of(ray);
+	float best = ANY ? limit : FLT_MAX;
+	int32_t best_prim = -1;
+	float best_u = 0, best_v = 0;
+	uint32_t node = tree.root;
+	int sp = 0;
+
+	for (;;) {
+		if (node & kLeafBit) {
+			uint32_t i = node & ~kLeafBit;
+			bool found = false;
+			for (;;) {
+				const float4 p0 = tree.prims[3 * (size_t)i];
+				const float4 p1 = tree.prims[3 * (size_t)i + 1];
+				const uint32_t flags = __float_as_uint(p0.w);
+				float t, u = 0, v = 0;
+				if (flags & kPrimSphere) {
+					if (COUNT) work.sph++;
+					t = test_sphere(mk(p0.x, p0.y, p0.z), p1.x, ray);
+				} else {
+					if (COUNT) work.tri++;
+					const float4 p2 = tree.prims[3 * (size_t)i + 2];
+					t = test_triangle(mk(p0.x, p0.y, p0.z), mk(p1.x, p1.y, p1.z), mk(p2.x, p2.y, p2.z), ray, u, v);
+				}
+				if (t < best) {           // strict: the first-visited primitive keeps a tie
+					best_prim = (int32_t)i;
+					if (ANY) {
+						found = true;
+						break;
+					}
+					best = t;
+					best_u = u;
+					best_v = v;
+				}
+				if (flags & kPrimLast)
+					break;
+				i++;
+			}
+			if (ANY && found)
+				break;
+			if (sp == 0)
+				break;
+			node = stack[(--sp) * kBlock];
+		} else {
+			if (COUNT) work.inner++;
+			const float4 *rec = tree.pairs + 4 * (size_t)node;
+			const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+			const uint32_t ref1 = __float_as_uint(q3.x), ref2 = __float_as_uint(q3.y);
+			const float d1 = test_box(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), ray, sg, best);
+			const float d2 = test_box(mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w), ray, sg, best);
+			uint32_t first, second;
+			bool hit_first, hit_second;
+			if (ANY) {
+				// first child first, no ordering (src/main.cpp:460-473)
+				first = ref1;
+				second = ref2;
+				hit_first = d1 < FLT_MAX;
+				hit_second = d2 < FLT_MAX;
+			} else {
+				// nearer child first; on equal distances the SECOND child is "near"
+				// (src/main.cpp:391-401)
+				const bool one_near = d1 < d2;
+				first = one_near ? ref1 : ref2;
+				second = one_near ? ref2 : ref1;
+				hit_first = (one_near ? d1 : d2) < FLT_MAX;
+				hit_second = (one_near ? d2 : d1) < FLT_MAX;
+			}
+			if (hit_first) {
+				node = first;
+				if (hit_second && sp < depth) {      // sp == depth cannot happen on a validated tree
+					stack[sp * kBlock] = second;
+					sp++;
+				}
+			} else if (hit_second) {
+				node = second;
+			} else {
+				if (sp == 0)
+					break;
+				node = stack[(--sp) * kBlock];
+			}
+		}
+	}
+	hit.prim = best_prim;
+	hit.t = ANY ? 0.f : best;
+	hit.u = best_u;
+	hit.v = best_v;
+}
+
+}  // namespace rta

@@ -807,6 +807,7 @@ static inline int32_t nearest_hit(const orc_scene *sc, const ray_t *ray, hit_t *
 					if (t < best) {
 						best = t;
 						best_idx = i;
+						bu = bv = 0;      /* barycentrics are a triangle notion */
 					}
 				} else if (o->type == OBJ_TRIANGLE) {
 					cn->tri_tests++;

@@ -209,7 +209,8 @@ int64_t rta_shard_pixels(int32_t width, int32_t height, int32_t shard_index, int
 
 /* Device arithmetic probe for tests: out[i] = op(x[i], y[i]) evaluated on the
  * GPU with the kernels' own primitives.  op: 0 x/y, 1 sqrtf(x), 2 pm_sinf,
- * 3 pm_cosf, 4 pm_logf, 5 pm_powf(x,y), 6 fmaf(x,y,x), 7 x*y+x (unfused). */
+ * 3 pm_cosf, 4 pm_logf, 5 pm_powf(x,y), 6 fmaf(x,y,x), 7 x*y+x (unfused),
+ * 8 the traversal's reciprocal-based quotient of x by y. */
 int rta_debug_arith(rta_context *ctx, int op, const float *x, const float *y, float *out, int64_t n);
 
 void *rta_stream(rta_context *ctx);     /* the hipStream_t all work of the context is enqueued on */

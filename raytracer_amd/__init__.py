@@ -373,7 +373,7 @@ class Context:
         self._check(lib().rta_resolve(self._h, accum_ptr, width, height, samples, exposure, bgr_ptr, MEM_DEVICE))
 
     def arith(self, op, x, y=None):
-        ops = {"div": 0, "sqrt": 1, "sin": 2, "cos": 3, "log": 4, "pow": 5, "fma": 6, "muladd": 7}
+        ops = {"div": 0, "sqrt": 1, "sin": 2, "cos": 3, "log": 4, "pow": 5, "fma": 6, "muladd": 7, "quot": 8}
         x = np.ascontiguousarray(x, np.float32)
         y = np.ascontiguousarray(y if y is not None else np.ones_like(x), np.float32)
         out = np.empty_like(x)

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -67,11 +68,12 @@ struct rta_context {
 	bool have_scene = false;
 	DeviceBuffer pairs, prims, shade_prims, materials, lights;
 	uint32_t root_ref = 0;
+	bool tame = false;           // box coordinates allow the reciprocal slab test (traverse.hpp)
 	int stack_depth = 1;
 	int32_t n_prims = 0, n_lights = 0;
 
 	// wavefront workspace
-	DeviceBuffer ray0, ray1, hit, thr, col, acc, q_ray0, q_ray1, q_regen, shadow, partial, pixels, frame, bgr, counters;
+	DeviceBuffer ray0, ray1, hit, thr, col, acc, shadow, partial, pixels, frame, bgr, counters;
 	DeviceBuffer io_a, io_b, io_c;       // staging for host-pointer calls
 	Counters *host_counters = nullptr;    // pinned
 
@@ -167,6 +169,7 @@ struct Flattened {
 	std::vector<float4> pairs, prims, shade, mats, lights;
 	uint32_t root = 0;
 	int depth = 0;
+	bool tame = true;
 };
 
 inline float as_float(uint32_t u)
@@ -257,6 +260,14 @@ std::string flatten(const rta_scene_desc &d, Flattened &out)
 		return d.node_count[node] > 0 ? (kLeaf | (uint32_t)d.node_index[node]) : (uint32_t)pair_of[node];
 	};
 	out.root = ref_of(0);
+	// the reciprocal slab test needs every box coordinate to be zero or of
+	// ordinary magnitude (see ray_is_tame in traverse.hpp); NaN fails both tests
+	out.tame = true;
+	for (size_t k = 0; k < (size_t)d.n_nodes * 6; k++) {
+		const float m = std::fabs(d.node_bounds[k]);
+		if (!(m == 0.f || (m >= 0x1p-78f && m <= 0x1p40f)))
+			out.tame = false;
+	}
 	out.pairs.resize(std::max<size_t>(inner_order.size(), 1) * 4, make_float4(0, 0, 0, 0));
 	for (size_t p = 0; p < inner_order.size(); p++) {
 		int32_t l = d.node_index[inner_order[p]], r = l + 1;
@@ -319,7 +330,7 @@ int upload_vec(rta_context *ctx, DeviceBuffer &buf, const std::vector<T> &v)
 
 TreeRef tree_of(const rta_context *ctx)
 {
-	return TreeRef{ctx->pairs.as<const float4>(), ctx->prims.as<const float4>(), ctx->root_ref};
+	return TreeRef{ctx->pairs.as<const float4>(), ctx->prims.as<const float4>(), ctx->root_ref, ctx->tame ? 1u : 0u};
 }
 
 // Owned pixels in walk order: tiles row-major, pixels row-major inside a tile,
@@ -361,6 +372,7 @@ int rta_upload_scene(rta_context *ctx, const rta_scene_desc *desc)
 		return rc;
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // the staging vectors die with this call
 	ctx->root_ref = f.root;
+	ctx->tame = f.tame;
 	ctx->stack_depth = f.depth;
 	ctx->n_prims = desc->n_prims;
 	ctx->n_lights = desc->n_lights;
@@ -536,9 +548,6 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	HIP_TRY(ctx, ctx->thr.reserve(S * 16));
 	HIP_TRY(ctx, ctx->col.reserve(S * 16));
 	HIP_TRY(ctx, ctx->acc.reserve(S * 16));
-	HIP_TRY(ctx, ctx->q_ray0.reserve(S * 4));
-	HIP_TRY(ctx, ctx->q_ray1.reserve(S * 4));
-	HIP_TRY(ctx, ctx->q_regen.reserve(S * 4));
 	if (ctx->n_lights > 0)
 		HIP_TRY(ctx, ctx->shadow.reserve(S * 48));
 	HIP_TRY(ctx, ctx->partial.reserve(std::max<size_t>(n_items, 1) * 16));
@@ -576,9 +585,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	a.thr = ctx->thr.as<float4>();
 	a.col = ctx->col.as<float4>();
 	a.acc = ctx->acc.as<float4>();
-	a.q_ray[0] = ctx->q_ray0.as<uint32_t>();
-	a.q_ray[1] = ctx->q_ray1.as<uint32_t>();
-	a.q_regen = ctx->q_regen.as<uint32_t>();
+	a.n_slots = n_slots;
 	a.shadow = ctx->shadow.as<float4>();
 	a.cnt = ctx->counters.as<Counters>();
 	a.partial = ctx->partial.as<float4>();
@@ -622,7 +629,6 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		HIP_TRY_R(hipMemcpyAsync(ctx->pixels.ptr, px.data(), (size_t)n_owned * 4, hipMemcpyHostToDevice, s));
 	Counters init;
 	memset(&init, 0, sizeof init);
-	init.n_regen = n_slots;
 	init.live = n_slots;
 	*ctx->host_counters = init;
 	HIP_TRY_R(hipMemcpyAsync(ctx->counters.ptr, ctx->host_counters, sizeof(Counters), hipMemcpyHostToDevice, s));
@@ -631,57 +637,44 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	HIP_TRY_R(hipEventRecord(ev_begin, s));
 	launch_init_slots(s, a, n_slots);
 
-	// The wavefront loop.  Queue lengths live on the device; the host only
-	// learns them every `poll` steps, to shrink the launch bound and to notice
-	// the end.  `bound` is an upper limit on every queue's length.
-	uint32_t bound = n_slots;
+	// The wavefront loop.  Progress lives on the device; the host reads it back
+	// every `poll` steps only to notice the end (steps past the end find every
+	// slot retired and do nothing).
 	const int poll = 16;
-	int cur = 0;
 	uint64_t steps = 0;
 	bool done = n_items == 0;
+	auto timed = [&](int kind, auto &&launch) -> hipError_t {
+		if (!time_kernels) {
+			launch();
+			return hipSuccess;
+		}
+		hipEvent_t e0 = nullptr, e1 = nullptr;
+		hipError_t e;
+		if ((e = hipEventCreate(&e0)) != hipSuccess)
+			return e;
+		ev_pool.push_back(e0);
+		if ((e = hipEventCreate(&e1)) != hipSuccess)
+			return e;
+		ev_pool.push_back(e1);
+		ev_kind.push_back(kind);
+		if ((e = hipEventRecord(e0, s)) != hipSuccess)
+			return e;
+		launch();
+		return hipEventRecord(e1, s);
+	};
 	while (!done) {
 		for (int k = 0; k < poll; k++) {
-			launch_generate(s, a, cur, bound);
-			if (time_kernels) {
-				hipEvent_t e0, e1;
-				HIP_TRY_R(hipEventCreate(&e0));
-				ev_pool.push_back(e0);
-				HIP_TRY_R(hipEventCreate(&e1));
-				ev_pool.push_back(e1);
-				ev_kind.push_back(0);
-				HIP_TRY_R(hipEventRecord(e0, s));
-				launch_intersect(s, a, cur, bound, ctx->stack_depth, count_work);
-				HIP_TRY_R(hipEventRecord(e1, s));
-			} else {
-				launch_intersect(s, a, cur, bound, ctx->stack_depth, count_work);
-			}
-			launch_shade(s, a, cur, bound);
-			if (lights) {
-				if (time_kernels) {
-					hipEvent_t e0, e1;
-					HIP_TRY_R(hipEventCreate(&e0));
-					ev_pool.push_back(e0);
-					HIP_TRY_R(hipEventCreate(&e1));
-					ev_pool.push_back(e1);
-					ev_kind.push_back(1);
-					HIP_TRY_R(hipEventRecord(e0, s));
-					launch_shadow(s, a, bound, ctx->stack_depth, count_work);
-					HIP_TRY_R(hipEventRecord(e1, s));
-				} else {
-					launch_shadow(s, a, bound, ctx->stack_depth, count_work);
-				}
-			}
-			cur ^= 1;
+			launch_generate(s, a);
+			HIP_TRY_R(timed(0, [&] { launch_intersect(s, a, ctx->stack_depth, count_work); }));
+			launch_shade(s, a);
+			if (lights)
+				HIP_TRY_R(timed(1, [&] { launch_shadow(s, a, n_slots, ctx->stack_depth, count_work); }));
 			steps++;
 		}
 		HIP_TRY_R(hipGetLastError());
 		HIP_TRY_R(hipMemcpyAsync(ctx->host_counters, ctx->counters.ptr, sizeof(Counters), hipMemcpyDeviceToHost, s));
 		HIP_TRY_R(hipStreamSynchronize(s));
-		const uint32_t live = ctx->host_counters->live;
-		if (live == 0)
-			done = true;
-		else
-			bound = std::min(bound, (live + 63) / 64 * 64);
+		done = ctx->host_counters->live == 0;
 	}
 
 	const uint32_t blocks = n_blocks;

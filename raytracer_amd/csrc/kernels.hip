@@ -1,7 +1,6 @@
 // HIP kernels of the wavefront path tracer (gfx950, wave64) and their
 // launchers.  The reference's per-pixel loop (src/main.cpp:657-714) becomes
-// four kernels per wavefront step that talk through compacted queues of path
-// slots:
+// four kernels per wavefront step over a fixed pool of path slots:
 //
 //   generate   retire finished samples into their block sum, hand out the next
 //              sample block, draw the camera ray (src/main.cpp:663-687)
@@ -19,6 +18,14 @@
 // and summed strictly in order; blocks are handed out through one atomic
 // counter.  Results therefore depend only on (seed, pixel, block), never on the
 // schedule.
+//
+// Lane i of every generate/intersect/shade launch works on slot i, so all slot
+// state (six float4 arrays) is read and written fully coalesced, and because a
+// finished path is replaced in place by its block's next camera sample every
+// live slot carries exactly one ray per step: the closest-hit "queue" is the
+// slot array itself and never has holes until the work items run out.  The
+// occlusion queries, which only some lanes issue, do go through a queue that is
+// compacted with a wave64 ballot + prefix count and one atomic per wave.
 
 #include "kernels.hpp"
 
@@ -30,6 +37,9 @@ namespace rta {
 namespace {
 
 constexpr uint32_t kNoItem = 0xffffffffu;
+// slot states kept in the bounce word (ray1.w): a bounce number, or
+constexpr uint32_t kRetired = 0xfffffffeu;     // no work item left for this slot
+constexpr uint32_t kEnded = 0xffffffffu;       // path finished; generate takes over
 
 RTA_DEV float4 f4(V3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
 RTA_DEV float4 f4u(V3 v, uint32_t w) { return make_float4(v.x, v.y, v.z, __uint_as_float(w)); }
@@ -61,116 +71,113 @@ RTA_DEV void count_flush(Counters *cnt, const WorkCount &wc)
 
 // ------------------------------------------------------------------ generate
 
-__global__ __launch_bounds__(kBlock) void k_generate(const RenderArgs a, const int cur)
+__global__ __launch_bounds__(kBlock) void k_generate(const RenderArgs a)
 {
-	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-	const uint32_t n = a.cnt->n_regen;
-	bool push = false;
-	uint32_t slot = 0;
-	if (i < n) {
-		slot = a.q_regen[i];
-		float4 A = a.acc[slot];
-		float4 C = a.col[slot];
-		uint32_t rng = __float_as_uint(a.thr[slot].w);
-		uint32_t item = __float_as_uint(A.w);
-		uint32_t done = __float_as_uint(C.w);
-		if (item != kNoItem) {
-			// the finished sample joins its block sum (src/main.cpp:689)
-			A.x += C.x;
-			A.y += C.y;
-			A.z += C.z;
-			done++;
-			const uint32_t block = item / a.n_owned;
-			const uint32_t first = block * a.sps;
-			const uint32_t len = a.spp - first < a.sps ? a.spp - first : a.sps;
-			if (done >= len) {
-				a.partial[item] = make_float4(A.x, A.y, A.z, 0.f);
-				item = kNoItem;
-			}
-		}
-		if (item == kNoItem) {
-			const uint32_t got = atomicAdd(&a.cnt->next_item, 1u);
-			if (got < a.n_items) {
-				item = got;
-				const uint32_t block = item / a.n_owned;
-				const uint32_t pixel = (uint32_t)a.pixels[item - block * a.n_owned];
-				rng = stream_seed(a.seed, pixel, block);
-				A.x = A.y = A.z = 0.f;
-				done = 0;
-			} else {
-				atomicSub(&a.cnt->live, 1u);
-			}
-		}
-		A.w = __uint_as_float(item);
-		a.acc[slot] = A;
-		if (item != kNoItem) {
-			const uint32_t block = item / a.n_owned;
-			const uint32_t pixel = (uint32_t)a.pixels[item - block * a.n_owned];
-			const uint32_t pu = pixel % a.width, pv = pixel / a.width;
-			const V3 cam_o = mk(a.cam.origin[0], a.cam.origin[1], a.cam.origin[2]);
-			V3 origin = cam_o;
-			if (a.cam.defocus_angle > 0) {
-				// src/main.cpp:105-113,665-669; the accept test is x*y < 1 as written there
-				float lx, ly;
-				for (;;) {
-					lx = rng_float(rng) * 2 - 1;
-					ly = rng_float(rng) * 2 - 1;
-					if (lx * ly < 1)
-						break;
-				}
-				const V3 lu = mk(a.cam.lens_u[0], a.cam.lens_u[1], a.cam.lens_u[2]);
-				const V3 lv = mk(a.cam.lens_v[0], a.cam.lens_v[1], a.cam.lens_v[2]);
-				origin = (cam_o + lu * lx) + lv * ly;
-			}
-			// Gaussian pixel filter by Box-Muller, sigma = 0.5 px (src/main.cpp:674-683)
-			float u1;
-			do {
-				u1 = rng_float(rng);
-			} while (u1 == 0);
-			const float u2 = rng_float(rng);
-			const float radius = .5f * __builtin_sqrtf(-2 * pm_logf(u1));
-			const float ju = radius * pm_cosf(2 * kPiF * u2);
-			const float jv = radius * pm_sinf(2 * kPiF * u2);
-			const V3 ul = mk(a.cam.upper_left[0], a.cam.upper_left[1], a.cam.upper_left[2]);
-			const V3 du = mk(a.cam.du[0], a.cam.du[1], a.cam.du[2]);
-			const V3 dv = mk(a.cam.dv[0], a.cam.dv[1], a.cam.dv[2]);
-			const V3 target = (ul + du * ((float)pu + .5f + ju)) + dv * ((float)pv + .5f + jv);
-			const V3 dir = unit(target - origin);
-			a.ray0[slot] = make_float4(origin.x, origin.y, origin.z, dir.x);
-			a.ray1[slot] = make_float4(dir.y, dir.z, 1.f, __uint_as_float(0u));     // bsdf_pdf = 1, bounce 0
-			a.thr[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(rng));
-			a.col[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(done));
-			push = true;
+	const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+	if (slot >= a.n_slots)
+		return;
+	float4 R1 = a.ray1[slot];
+	if (__float_as_uint(R1.w) != kEnded)
+		return;
+	float4 A = a.acc[slot];
+	float4 C = a.col[slot];
+	uint32_t rng = __float_as_uint(a.thr[slot].w);
+	uint32_t item = __float_as_uint(A.w);
+	uint32_t done = __float_as_uint(C.w);
+	if (item != kNoItem) {
+		// the finished sample joins its block sum (src/main.cpp:689)
+		A.x += C.x;
+		A.y += C.y;
+		A.z += C.z;
+		done++;
+		const uint32_t block = item / a.n_owned;
+		const uint32_t first = block * a.sps;
+		const uint32_t len = a.spp - first < a.sps ? a.spp - first : a.sps;
+		if (done >= len) {
+			a.partial[item] = make_float4(A.x, A.y, A.z, 0.f);
+			item = kNoItem;
 		}
 	}
-	const uint32_t at = queue_push(push, &a.cnt->n_ray[cur]);
-	if (push)
-		a.q_ray[cur][at] = slot;
+	if (item == kNoItem) {
+		const uint32_t got = atomicAdd(&a.cnt->next_item, 1u);
+		if (got < a.n_items) {
+			item = got;
+			const uint32_t block = item / a.n_owned;
+			const uint32_t pixel = (uint32_t)a.pixels[item - block * a.n_owned];
+			rng = stream_seed(a.seed, pixel, block);
+			A.x = A.y = A.z = 0.f;
+			done = 0;
+		} else {
+			atomicSub(&a.cnt->live, 1u);
+		}
+	}
+	A.w = __uint_as_float(item);
+	a.acc[slot] = A;
+	if (item == kNoItem) {
+		R1.w = __uint_as_float(kRetired);
+		a.ray1[slot] = R1;
+		return;
+	}
+	const uint32_t block = item / a.n_owned;
+	const uint32_t pixel = (uint32_t)a.pixels[item - block * a.n_owned];
+	const uint32_t pu = pixel % a.width, pv = pixel / a.width;
+	const V3 cam_o = mk(a.cam.origin[0], a.cam.origin[1], a.cam.origin[2]);
+	V3 origin = cam_o;
+	if (a.cam.defocus_angle > 0) {
+		// src/main.cpp:105-113,665-669; the accept test is x*y < 1 as written there
+		float lx, ly;
+		for (;;) {
+			lx = rng_float(rng) * 2 - 1;
+			ly = rng_float(rng) * 2 - 1;
+			if (lx * ly < 1)
+				break;
+		}
+		const V3 lu = mk(a.cam.lens_u[0], a.cam.lens_u[1], a.cam.lens_u[2]);
+		const V3 lv = mk(a.cam.lens_v[0], a.cam.lens_v[1], a.cam.lens_v[2]);
+		origin = (cam_o + lu * lx) + lv * ly;
+	}
+	// Gaussian pixel filter by Box-Muller, sigma = 0.5 px (src/main.cpp:674-683)
+	float u1;
+	do {
+		u1 = rng_float(rng);
+	} while (u1 == 0);
+	const float u2 = rng_float(rng);
+	const float radius = .5f * __builtin_sqrtf(-2 * pm_logf(u1));
+	const float ju = radius * pm_cosf(2 * kPiF * u2);
+	const float jv = radius * pm_sinf(2 * kPiF * u2);
+	const V3 ul = mk(a.cam.upper_left[0], a.cam.upper_left[1], a.cam.upper_left[2]);
+	const V3 du = mk(a.cam.du[0], a.cam.du[1], a.cam.du[2]);
+	const V3 dv = mk(a.cam.dv[0], a.cam.dv[1], a.cam.dv[2]);
+	const V3 target = (ul + du * ((float)pu + .5f + ju)) + dv * ((float)pv + .5f + jv);
+	const V3 dir = unit(target - origin);
+	a.ray0[slot] = make_float4(origin.x, origin.y, origin.z, dir.x);
+	a.ray1[slot] = make_float4(dir.y, dir.z, 1.f, __uint_as_float(0u));     // bsdf_pdf = 1, bounce 0
+	a.thr[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(rng));
+	a.col[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(done));
 }
 
 // ------------------------------------------------------------------ intersect
 
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_intersect(const RenderArgs a, const int cur, const int depth)
+__global__ __launch_bounds__(kBlock) void k_intersect(const RenderArgs a, const int depth)
 {
 	extern __shared__ uint32_t lds_stack[];
-	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-	const uint32_t n = a.cnt->n_ray[cur];
-	if (i == 0) {
-		// queues that nobody reads or appends to during this launch
-		a.cnt->n_regen = 0;
-		a.cnt->n_ray[cur ^ 1] = 0;
-		a.cnt->n_shadow = 0;
-		a.cnt->rays += n;
+	const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+	if (slot == 0) {
+		// every live slot carries exactly one ray per step
+		a.cnt->rays += a.cnt->live;
+		a.cnt->n_shadow = 0;          // nobody reads or appends to it during this launch
 	}
 	WorkCount wc = {0, 0, 0};
-	if (i < n) {
-		const uint32_t slot = a.q_ray[cur][i];
-		const float4 r0 = a.ray0[slot], r1 = a.ray1[slot];
-		Ray ray = {mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y)};
-		HitRec h;
-		traverse_dyn<false, COUNT>(a.tree, ray, FLT_MAX, lds_stack + threadIdx.x, depth, h, wc);
-		a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
+	if (slot < a.n_slots) {
+		const float4 r1 = a.ray1[slot];
+		if (__float_as_uint(r1.w) < kRetired) {
+			const float4 r0 = a.ray0[slot];
+			Ray ray = {mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y)};
+			HitRec h;
+			traverse_dyn<false, COUNT>(a.tree, ray, FLT_MAX, lds_stack + threadIdx.x, depth, a.tree.tame != 0, h, wc);
+			a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
+		}
 	}
 	if (COUNT)
 		count_flush(a.cnt, wc);
@@ -178,18 +185,19 @@ __global__ __launch_bounds__(kBlock) void k_intersect(const RenderArgs a, const 
 
 // ------------------------------------------------------------------ shade
 
-__global__ __launch_bounds__(kBlock) void k_shade(const RenderArgs a, const int cur)
+__global__ __launch_bounds__(kBlock) void k_shade(const RenderArgs a)
 {
-	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-	const uint32_t n = a.cnt->n_ray[cur];
-	bool alive = false, ended = false, want_shadow = false;
-	uint32_t slot = 0;
+	const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+	bool want_shadow = false;
 	V3 sh_o = mk(0, 0, 0), sh_d = mk(0, 0, 0), sh_c = mk(0, 0, 0);
 	float sh_dist = 0;
+	float4 r1 = make_float4(0.f, 0.f, 0.f, __uint_as_float(kRetired));
+	if (slot < a.n_slots)
+		r1 = a.ray1[slot];
 
-	if (i < n) {
-		slot = a.q_ray[cur][i];
-		const float4 r0 = a.ray0[slot], r1 = a.ray1[slot];
+	if (__float_as_uint(r1.w) < kRetired) {
+		bool alive = false;
+		const float4 r0 = a.ray0[slot];
 		const float4 H = a.hit[slot];
 		float4 T = a.thr[slot];
 		float4 C = a.col[slot];
@@ -203,7 +211,6 @@ __global__ __launch_bounds__(kBlock) void k_shade(const RenderArgs a, const int 
 		if (prim < 0) {
 			// src/main.cpp:511-514
 			color = color + thr * mk(a.sky[0], a.sky[1], a.sky[2]);
-			ended = true;
 		} else {
 			const float t = H.y, bu = H.z, bv = H.w;
 			const float4 s0 = a.shade_prims[3 * (size_t)prim];
@@ -300,26 +307,20 @@ __global__ __launch_bounds__(kBlock) void k_shade(const RenderArgs a, const int 
 				a.ray0[slot] = make_float4(point.x, point.y, point.z, nd.x);
 				a.ray1[slot] = make_float4(nd.y, nd.z, s.pdf, __uint_as_float(bounce + 1));
 				alive = true;
-			} else {
-				ended = true;
 			}
 		}
+		if (!alive)
+			a.ray1[slot] = make_float4(r1.x, r1.y, r1.z, __uint_as_float(kEnded));
 		a.thr[slot] = f4u(thr, rng);
 		a.col[slot] = make_float4(color.x, color.y, color.z, C.w);
 	}
 
-	const uint32_t at_ray = queue_push(alive, &a.cnt->n_ray[cur ^ 1]);
-	if (alive)
-		a.q_ray[cur ^ 1][at_ray] = slot;
-	const uint32_t at_regen = queue_push(ended, &a.cnt->n_regen);
-	if (ended)
-		a.q_regen[at_regen] = slot;
 	if (a.n_lights > 0) {
 		const uint32_t at_sh = queue_push(want_shadow, &a.cnt->n_shadow);
 		if (want_shadow) {
 			float4 *e = a.shadow + 3 * (size_t)at_sh;
 			e[0] = f4(sh_o, sh_dist);
-			e[1] = f4u(sh_d, slot);
+			e[1] = f4u(sh_d, slot);      // slot < n_slots here: want_shadow implies a live lane
 			e[2] = f4(sh_c, 0.f);
 		}
 	}
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow(const RenderArgs a, const int
 		const float4 e0 = e[0], e1 = e[1], e2 = e[2];
 		Ray ray = {xyz(e0), xyz(e1)};
 		HitRec h;
-		traverse_dyn<true, COUNT>(a.tree, ray, e0.w, lds_stack + threadIdx.x, depth, h, wc);
+		traverse_dyn<true, COUNT>(a.tree, ray, e0.w, lds_stack + threadIdx.x, depth, a.tree.tame != 0, h, wc);
 		if (h.prim < 0) {
 			// src/main.cpp:569: the light's contribution joins the path radiance
 			const uint32_t slot = __float_as_uint(e1.w);
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(kBlock) void k_init_slots(const RenderArgs a, uint3
 	a.acc[i] = make_float4(0.f, 0.f, 0.f, __uint_as_float(kNoItem));
 	a.col[i] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
 	a.thr[i] = make_float4(1.f, 1.f, 1.f, __uint_as_float(1u));
-	a.q_regen[i] = i;
+	a.ray1[i] = make_float4(0.f, 0.f, 1.f, __uint_as_float(kEnded));
 }
 
 // ------------------------------------------------------------------ ray batches
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(kBlock) void k_batch_closest(const DeviceTree tree,
 		const float *r = rays + i * 6;
 		Ray ray = {mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5])};
 		HitRec h;
-		traverse_dyn<false, COUNT>(tree, ray, FLT_MAX, lds_stack + threadIdx.x, depth, h, wc);
+		traverse_dyn<false, COUNT>(tree, ray, FLT_MAX, lds_stack + threadIdx.x, depth, tree.tame != 0, h, wc);
 		rta_hit out;
 		out.prim = h.prim;
 		out.t = h.t;
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(kBlock) void k_batch_occluded(const DeviceTree tree
 	Ray ray = {mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5])};
 	HitRec h;
 	WorkCount wc = {0, 0, 0};
-	traverse_dyn<true, false>(tree, ray, tmax[i], lds_stack + threadIdx.x, depth, h, wc);
+	traverse_dyn<true, false>(tree, ray, tmax[i], lds_stack + threadIdx.x, depth, tree.tame != 0, h, wc);
 	out[i] = h.prim >= 0 ? 1 : 0;
 }
 
@@ -475,6 +476,7 @@ __global__ __launch_bounds__(kBlock) void k_arith(int op, const float *x, const 
 	case 4: r = pm_logf(a); break;
 	case 5: r = pm_powf(a, b); break;
 	case 6: r = __builtin_fmaf(a, b, a); break;
+	case 8: r = quotient(a, b, 1.f / b); break;
 	default: r = a * b + a; break;
 	}
 	out[i] = r;
@@ -492,24 +494,24 @@ void launch_init_slots(hipStream_t s, const RenderArgs &a, uint32_t n_slots)
 	hipLaunchKernelGGL(k_init_slots, dim3(blocks_for(n_slots)), dim3(kBlock), 0, s, a, n_slots);
 }
 
-void launch_generate(hipStream_t s, const RenderArgs &a, int cur, uint32_t bound)
+void launch_generate(hipStream_t s, const RenderArgs &a)
 {
-	hipLaunchKernelGGL(k_generate, dim3(blocks_for(bound)), dim3(kBlock), 0, s, a, cur);
+	hipLaunchKernelGGL(k_generate, dim3(blocks_for(a.n_slots)), dim3(kBlock), 0, s, a);
 }
 
-void launch_intersect(hipStream_t s, const RenderArgs &a, int cur, uint32_t bound, int depth, bool count)
+void launch_intersect(hipStream_t s, const RenderArgs &a, int depth, bool count)
 {
 	if (count)
-		hipLaunchKernelGGL(k_intersect<true>, dim3(blocks_for(bound)), dim3(kBlock), stack_bytes(depth), s, a, cur,
+		hipLaunchKernelGGL(k_intersect<true>, dim3(blocks_for(a.n_slots)), dim3(kBlock), stack_bytes(depth), s, a,
 		                   depth);
 	else
-		hipLaunchKernelGGL(k_intersect<false>, dim3(blocks_for(bound)), dim3(kBlock), stack_bytes(depth), s, a, cur,
+		hipLaunchKernelGGL(k_intersect<false>, dim3(blocks_for(a.n_slots)), dim3(kBlock), stack_bytes(depth), s, a,
 		                   depth);
 }
 
-void launch_shade(hipStream_t s, const RenderArgs &a, int cur, uint32_t bound)
+void launch_shade(hipStream_t s, const RenderArgs &a)
 {
-	hipLaunchKernelGGL(k_shade, dim3(blocks_for(bound)), dim3(kBlock), 0, s, a, cur);
+	hipLaunchKernelGGL(k_shade, dim3(blocks_for(a.n_slots)), dim3(kBlock), 0, s, a);
 }
 
 void launch_shadow(hipStream_t s, const RenderArgs &a, uint32_t bound, int depth, bool count)

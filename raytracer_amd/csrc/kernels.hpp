@@ -12,12 +12,10 @@ namespace rta {
 
 // Device-resident queue lengths and statistics.  One instance per context.
 struct Counters {
-	uint32_t n_ray[2];       // closest-hit queue, double buffered
-	uint32_t n_regen;        // slots whose path ended this step
 	uint32_t n_shadow;       // pending occlusion queries
 	uint32_t next_item;      // next (pixel, block) work item to hand out
 	uint32_t live;           // slots that still own or may get a work item
-	uint32_t pad[2];
+	uint32_t pad;
 	unsigned long long rays, shadow_rays;
 	unsigned long long inner, tri, sph;     // RTA_RENDER_COUNT_WORK only
 };
@@ -26,6 +24,7 @@ struct TreeRef {
 	const float4 *pairs;
 	const float4 *prims;
 	uint32_t root;
+	uint32_t tame;           // every box coordinate is 0 or within [2^-78, 2^40] in magnitude
 };
 
 // Everything a wavefront kernel needs, passed by value.
@@ -38,15 +37,14 @@ struct RenderArgs {
 
 	// per path slot
 	float4 *ray0;                  // origin xyz, direction x
-	float4 *ray1;                  // direction yz, pdf of the sampled direction, bounce
+	float4 *ray1;                  // direction yz, pdf of the sampled direction, bounce or slot state
 	float4 *hit;                   // primitive, t, u, v
 	float4 *thr;                   // throughput rgb, rng state
 	float4 *col;                   // path radiance rgb, samples finished in the current block
 	float4 *acc;                   // block sum rgb, work item
-	// queues
-	uint32_t *q_ray[2];
-	uint32_t *q_regen;
-	float4 *shadow;                // 3 per entry: (origin, limit) (direction, slot) (radiance, -)
+	uint32_t n_slots;
+	// occlusion queue, 3 per entry: (origin, limit) (direction, slot) (radiance, -)
+	float4 *shadow;
 	Counters *cnt;
 
 	float4 *partial;               // one block sum per work item
@@ -61,9 +59,9 @@ struct RenderArgs {
 };
 
 void launch_init_slots(hipStream_t s, const RenderArgs &a, uint32_t n_slots);
-void launch_generate(hipStream_t s, const RenderArgs &a, int cur, uint32_t bound);
-void launch_intersect(hipStream_t s, const RenderArgs &a, int cur, uint32_t bound, int depth, bool count);
-void launch_shade(hipStream_t s, const RenderArgs &a, int cur, uint32_t bound);
+void launch_generate(hipStream_t s, const RenderArgs &a);
+void launch_intersect(hipStream_t s, const RenderArgs &a, int depth, bool count);
+void launch_shade(hipStream_t s, const RenderArgs &a);
 void launch_shadow(hipStream_t s, const RenderArgs &a, uint32_t bound, int depth, bool count);
 void launch_sum_blocks(hipStream_t s, const float4 *partial, const int32_t *pixels, uint32_t n_owned, uint32_t n_blocks,
                        float *frame);

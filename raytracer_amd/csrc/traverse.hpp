@@ -96,6 +96,32 @@ RTA_DEV void slab(float lo, float hi, float o, float d, bool negative, float &tm
 	tmax = lesser(t2, tmax);
 }
 
+// The same quotient from a precomputed reciprocal r = RN(1/d): multiply, then
+// two residual corrections with fused multiply-adds.  The first correction
+// leaves a faithful quotient, and a faithful quotient corrected once more with
+// the correctly rounded reciprocal IS the correctly rounded quotient
+// (Markstein's theorem), provided nothing under- or overflows on the way.
+// rays_are_tame() establishes that proviso per ray; the quotient may differ
+// from n/d in the sign of a zero only, which no comparison below can see.
+RTA_DEV float quotient(float n, float d, float r)
+{
+	float q = n * r;
+	float e = __builtin_fmaf(-d, q, n);
+	q = __builtin_fmaf(e, r, q);
+	e = __builtin_fmaf(-d, q, n);
+	return __builtin_fmaf(e, r, q);
+}
+
+RTA_DEV void slab_tame(float lo, float hi, float o, float d, float r, bool negative, float &tmin, float &tmax)
+{
+	float near_plane = negative ? hi : lo;
+	float far_plane = negative ? lo : hi;
+	float t1 = quotient(near_plane - o, d, r);
+	float t2 = quotient(far_plane - o, d, r);
+	tmin = greater(t1, tmin);
+	tmax = lesser(t2, tmax);
+}
+
 struct RaySigns {
 	bool x, y, z;
 };
@@ -104,6 +130,23 @@ RTA_DEV RaySigns signs_of(const Ray &r)
 {
 	return RaySigns{(__float_as_uint(r.d.x) >> 31) != 0, (__float_as_uint(r.d.y) >> 31) != 0,
 	                (__float_as_uint(r.d.z) >> 31) != 0};
+}
+
+// True when every slab quotient of this ray can take the reciprocal route: each
+// direction component has magnitude in [2^-40, 2^40] and each origin component
+// is zero or has magnitude in [2^-50, 2^40].  Together with the scene-side
+// condition checked at upload (every box coordinate is zero or has magnitude in
+// [2^-78, 2^40]) a numerator plane - o is then zero or at least 2^-78 in
+// magnitude, and quotient() stays clear of subnormals and overflow.
+RTA_DEV bool component_tame(float d, float o)
+{
+	const float ad = __builtin_fabsf(d), ao = __builtin_fabsf(o);
+	return ad >= 0x1p-40f && ad <= 0x1p40f && (ao == 0.f || (ao >= 0x1p-50f && ao <= 0x1p40f));
+}
+
+RTA_DEV bool ray_is_tame(const Ray &r)
+{
+	return component_tame(r.d.x, r.o.x) && component_tame(r.d.y, r.o.y) && component_tame(r.d.z, r.o.z);
 }
 
 RTA_DEV float test_box(V3 lo, V3 hi, const Ray &r, RaySigns s, float max_t)
@@ -115,66 +158,54 @@ RTA_DEV float test_box(V3 lo, V3 hi, const Ray &r, RaySigns s, float max_t)
 	return (tmax >= tmin && tmin < max_t && tmax > 0) ? tmin : FLT_MAX;
 }
 
+RTA_DEV float test_box_tame(V3 lo, V3 hi, const Ray &r, V3 rcp, RaySigns s, float max_t)
+{
+	float tmin = 0.f, tmax = FLT_MAX;
+	slab_tame(lo.x, hi.x, r.o.x, r.d.x, rcp.x, s.x, tmin, tmax);
+	slab_tame(lo.y, hi.y, r.o.y, r.d.y, rcp.y, s.y, tmin, tmax);
+	slab_tame(lo.z, hi.z, r.o.z, r.d.z, rcp.z, s.z, tmin, tmax);
+	return (tmax >= tmin && tmin < max_t && tmax > 0) ? tmin : FLT_MAX;
+}
+
 // Traversal of src/main.cpp:332-422 (closest, ANY = false) and :424-478 (any
 // hit, ANY = true).  `stack` points at this lane's column of an LDS array laid
 // out [depth][kBlock], so consecutive lanes hit consecutive banks.  `depth` is
 // the number of entries the column has (the launch sizes dynamic LDS from it);
 // upload guarantees the tree never needs more.  For ANY, `limit` is the
 // distance bound and the result is hit.prim >= 0.
+//
+// The loop is split in two phases so that a wave64 spends its time converged:
+// every lane first descends inner nodes until it holds a leaf (or runs out of
+// work), then the lanes holding leaves test primitives together.
 template <bool ANY, bool COUNT>
 RTA_DEV void traverse_dyn(const DeviceTree &tree, const Ray &ray, float limit, uint32_t *stack, const int depth,
-                          HitRec &hit, WorkCount &work)
+                          const bool scene_tame, HitRec &hit, WorkCount &work)
 {
 	const RaySigns sg = signs_of(ray);
+	const bool tame = scene_tame && ray_is_tame(ray);
+	// correctly rounded reciprocals; garbage (unused) for rays that are not tame
+	const V3 rcp = mk(1.f / ray.d.x, 1.f / ray.d.y, 1.f / ray.d.z);
 	float best = ANY ? limit : FLT_MAX;
 	int32_t best_prim = -1;
 	float best_u = 0, best_v = 0;
 	uint32_t node = tree.root;
 	int sp = 0;
+	bool more = true;
 
-	for (;;) {
-		if (node & kLeafBit) {
-			uint32_t i = node & ~kLeafBit;
-			bool found = false;
-			for (;;) {
-				const float4 p0 = tree.prims[3 * (size_t)i];
-				const float4 p1 = tree.prims[3 * (size_t)i + 1];
-				const uint32_t flags = __float_as_uint(p0.w);
-				float t, u = 0, v = 0;
-				if (flags & kPrimSphere) {
-					if (COUNT) work.sph++;
-					t = test_sphere(mk(p0.x, p0.y, p0.z), p1.x, ray);
-				} else {
-					if (COUNT) work.tri++;
-					const float4 p2 = tree.prims[3 * (size_t)i + 2];
-					t = test_triangle(mk(p0.x, p0.y, p0.z), mk(p1.x, p1.y, p1.z), mk(p2.x, p2.y, p2.z), ray, u, v);
-				}
-				if (t < best) {           // strict: the first-visited primitive keeps a tie
-					best_prim = (int32_t)i;
-					if (ANY) {
-						found = true;
-						break;
-					}
-					best = t;
-					best_u = u;
-					best_v = v;
-				}
-				if (flags & kPrimLast)
-					break;
-				i++;
-			}
-			if (ANY && found)
-				break;
-			if (sp == 0)
-				break;
-			node = stack[(--sp) * kBlock];
-		} else {
+	while (more) {
+		while (more && !(node & kLeafBit)) {
 			if (COUNT) work.inner++;
 			const float4 *rec = tree.pairs + 4 * (size_t)node;
 			const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
 			const uint32_t ref1 = __float_as_uint(q3.x), ref2 = __float_as_uint(q3.y);
-			const float d1 = test_box(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), ray, sg, best);
-			const float d2 = test_box(mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w), ray, sg, best);
+			float d1, d2;
+			if (tame) {
+				d1 = test_box_tame(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), ray, rcp, sg, best);
+				d2 = test_box_tame(mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w), ray, rcp, sg, best);
+			} else {
+				d1 = test_box(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), ray, sg, best);
+				d2 = test_box(mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w), ray, sg, best);
+			}
 			uint32_t first, second;
 			bool hit_first, hit_second;
 			if (ANY) {
@@ -200,11 +231,48 @@ RTA_DEV void traverse_dyn(const DeviceTree &tree, const Ray &ray, float limit, u
 				}
 			} else if (hit_second) {
 				node = second;
-			} else {
-				if (sp == 0)
-					break;
+			} else if (sp > 0) {
 				node = stack[(--sp) * kBlock];
+			} else {
+				more = false;
 			}
+		}
+		if (!more)
+			break;
+
+		uint32_t i = node & ~kLeafBit;
+		for (;;) {
+			const float4 p0 = tree.prims[3 * (size_t)i];
+			const float4 p1 = tree.prims[3 * (size_t)i + 1];
+			const uint32_t flags = __float_as_uint(p0.w);
+			float t, u = 0, v = 0;
+			if (flags & kPrimSphere) {
+				if (COUNT) work.sph++;
+				t = test_sphere(mk(p0.x, p0.y, p0.z), p1.x, ray);
+			} else {
+				if (COUNT) work.tri++;
+				const float4 p2 = tree.prims[3 * (size_t)i + 2];
+				t = test_triangle(mk(p0.x, p0.y, p0.z), mk(p1.x, p1.y, p1.z), mk(p2.x, p2.y, p2.z), ray, u, v);
+			}
+			if (t < best) {           // strict: the first-visited primitive keeps a tie
+				best_prim = (int32_t)i;
+				if (ANY) {
+					more = false;
+					break;
+				}
+				best = t;
+				best_u = u;
+				best_v = v;
+			}
+			if (flags & kPrimLast)
+				break;
+			i++;
+		}
+		if (more) {
+			if (sp > 0)
+				node = stack[(--sp) * kBlock];
+			else
+				more = false;
 		}
 	}
 	hit.prim = best_prim;

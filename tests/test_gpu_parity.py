@@ -52,6 +52,32 @@ def test_device_arithmetic_is_ieee(gpu):
         assert ok.mean() > 0.9999      # double rounding of the fp64 emulation is the only slack
 
 
+def test_reciprocal_quotient_is_correctly_rounded(gpu):
+    """The slab test's multiply + two fused corrections must equal IEEE division
+    wherever the traversal uses it: |d| in [2^-40, 2^40], numerator 0 or of
+    magnitude in [2^-78, 2^41]."""
+    rng = np.random.default_rng(3)
+    n = 4_000_000
+    def spread(count, lo_exp, hi_exp):
+        mant = rng.integers(0, 1 << 23, count, dtype=np.uint32)
+        exp = rng.integers(lo_exp + 127, hi_exp + 127, count, dtype=np.uint32)
+        sign = rng.integers(0, 2, count, dtype=np.uint32)
+        return ((sign << 31) | (exp << 23) | mant).view(np.float32)
+    num = np.concatenate([spread(n, -78, 41), rng.standard_normal(n).astype(np.float32), np.zeros(16, np.float32)])
+    den = np.concatenate([spread(n, -40, 40), rng.standard_normal(n).astype(np.float32) + np.float32(1e-6),
+                          spread(16, -40, 40)])
+    # denominators with an all-ones significand, the classic hard case for reciprocal methods
+    ones = (np.uint32(0x7fffff) | (rng.integers(87, 167, 4096, dtype=np.uint32) << 23)).view(np.float32)
+    num = np.concatenate([num, spread(4096, -20, 20)])
+    den = np.concatenate([den, ones])
+    keep = (np.abs(den) >= 2.0 ** -40) & (np.abs(den) <= 2.0 ** 40)
+    num, den = num[keep], den[keep]
+    want = (num / den).astype(np.float32)
+    got = gpu.arith("quot", num, den)
+    same = (bits(got) == bits(want)) | ((got == 0) & (want == 0))
+    assert same.all(), f"{(~same).sum()} of {same.size} quotients differ, e.g. {num[~same][:3]} / {den[~same][:3]}"
+
+
 def test_portable_math_matches_cpu(gpu):
     rng = np.random.default_rng(2)
     n = 300000

@@ -165,6 +165,8 @@ typedef struct {
 	int32_t slots;                /* paths in flight; <= 0: library default */
 	int32_t out_mem;              /* RTA_MEM_* of accum and bgr */
 	int32_t flags;                /* RTA_RENDER_* */
+	int32_t run_blocks;           /* consecutive sample blocks of a tile a wave takes at once (scheduling
+	                               * only, results do not depend on it); <= 0: library default */
 } rta_render_params;
 
 enum {

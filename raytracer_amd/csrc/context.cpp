@@ -73,7 +73,7 @@ struct rta_context {
 	int32_t n_prims = 0, n_lights = 0;
 
 	// wavefront workspace
-	DeviceBuffer ray0, ray1, hit, thr, col, acc, shadow, partial, pixels, frame, bgr, counters;
+	DeviceBuffer ray0, ray1, hit, thr, col, acc, meta, shadow, partial, pixels, frame, bgr, counters;
 	DeviceBuffer io_a, io_b, io_c;       // staging for host-pointer calls
 	Counters *host_counters = nullptr;    // pinned
 
@@ -333,9 +333,10 @@ TreeRef tree_of(const rta_context *ctx)
 	return TreeRef{ctx->pairs.as<const float4>(), ctx->prims.as<const float4>(), ctx->root_ref, ctx->tame ? 1u : 0u};
 }
 
-// Owned pixels in walk order: tiles row-major, pixels row-major inside a tile,
-// clipped to the frame.
-void shard_pixels(int32_t w, int32_t h, int32_t shard, int32_t n_shards, std::vector<int32_t> &out)
+// Owned pixels in walk order: tiles row-major, pixels row-major inside a tile.
+// With `padded`, every tile contributes exactly 64 entries and the positions
+// that fall outside the frame hold -1; otherwise those are dropped.
+void shard_pixels(int32_t w, int32_t h, int32_t shard, int32_t n_shards, bool padded, std::vector<int32_t> &out)
 {
 	out.clear();
 	const int32_t tx = (w + kTile - 1) / kTile, ty = (h + kTile - 1) / kTile;
@@ -343,9 +344,13 @@ void shard_pixels(int32_t w, int32_t h, int32_t shard, int32_t n_shards, std::ve
 		if (t % n_shards != shard)
 			continue;
 		const int32_t x0 = (t % tx) * kTile, y0 = (t / tx) * kTile;
-		for (int32_t y = y0; y < std::min(y0 + kTile, h); y++)
-			for (int32_t x = x0; x < std::min(x0 + kTile, w); x++)
-				out.push_back(y * w + x);
+		for (int32_t y = y0; y < y0 + kTile; y++)
+			for (int32_t x = x0; x < x0 + kTile; x++) {
+				if (x < w && y < h)
+					out.push_back(y * w + x);
+				else if (padded)
+					out.push_back(-1);
+			}
 	}
 }
 
@@ -385,7 +390,7 @@ int64_t rta_shard_pixels(int32_t width, int32_t height, int32_t shard_index, int
 	if (width <= 0 || height <= 0 || shard_count <= 0 || shard_index < 0 || shard_index >= shard_count)
 		return RTA_E_INVALID;
 	std::vector<int32_t> px;
-	shard_pixels(width, height, shard_index, shard_count, px);
+	shard_pixels(width, height, shard_index, shard_count, false, px);
 	if (out)
 		memcpy(out, px.data(), px.size() * sizeof(int32_t));
 	return (int64_t)px.size();
@@ -522,22 +527,28 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		return ctx->fail(RTA_E_LIMIT, "frame too large");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 
-	std::vector<int32_t> px;
-	shard_pixels(p->width, p->height, p->shard_index, n_shards, px);
-	const uint32_t n_owned = (uint32_t)px.size();
+	std::vector<int32_t> px;          // 64 entries per owned tile, -1 outside the frame
+	shard_pixels(p->width, p->height, p->shard_index, n_shards, true, px);
+	const uint32_t n_pad = (uint32_t)px.size();
+	const uint32_t n_tiles = n_pad / 64;
+	uint32_t n_owned = 0;
+	for (int32_t q : px)
+		n_owned += q >= 0;
 	const uint32_t spp = (uint32_t)p->samples;
 	const uint32_t sps = p->samples_per_stream <= 0 ? spp : std::min((uint32_t)p->samples_per_stream, spp);
 	const uint32_t n_blocks = (spp + sps - 1) / sps;
-	const uint64_t items64 = (uint64_t)n_owned * n_blocks;
+	const uint32_t run_blocks = p->run_blocks > 0 ? std::min((uint32_t)p->run_blocks, n_blocks) : std::min(2u, n_blocks);
+	const uint32_t n_runs = (n_blocks + run_blocks - 1) / run_blocks;
+	const uint64_t items64 = (uint64_t)n_tiles * n_runs;          // (tile, block run) pairs, one per wave at a time
 	const size_t frame_px = (size_t)p->width * p->height;
 	rta_stats st;
 	memset(&st, 0, sizeof st);
 
-	uint32_t n_slots = p->slots > 0 ? (uint32_t)p->slots : (1u << 21);
-	n_slots = (uint32_t)std::min<uint64_t>(n_slots, std::max<uint64_t>(items64, 1));
-	n_slots = (n_slots + 63) / 64 * 64;
-	if (items64 + n_slots >= 0xffffffffull)
-		return ctx->fail(RTA_E_LIMIT, "pixels x sample blocks exceeds 2^32; raise samples_per_stream");
+	uint64_t want_slots = p->slots > 0 ? (uint64_t)p->slots : (1u << 21);
+	want_slots = std::min<uint64_t>((want_slots + 63) / 64, std::max<uint64_t>(items64, 1)) * 64;
+	const uint32_t n_slots = (uint32_t)want_slots;
+	if (items64 + n_slots >= 0xffffffffull || (uint64_t)n_blocks * n_pad >= 0xffffffffull)
+		return ctx->fail(RTA_E_LIMIT, "tiles x sample blocks exceeds 2^32; raise samples_per_stream");
 	const uint32_t n_items = (uint32_t)items64;
 
 	// workspace (grow-only, reused across calls)
@@ -548,10 +559,11 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	HIP_TRY(ctx, ctx->thr.reserve(S * 16));
 	HIP_TRY(ctx, ctx->col.reserve(S * 16));
 	HIP_TRY(ctx, ctx->acc.reserve(S * 16));
+	HIP_TRY(ctx, ctx->meta.reserve(S * 16));
 	if (ctx->n_lights > 0)
 		HIP_TRY(ctx, ctx->shadow.reserve(S * 48));
-	HIP_TRY(ctx, ctx->partial.reserve(std::max<size_t>(n_items, 1) * 16));
-	HIP_TRY(ctx, ctx->pixels.reserve(std::max<size_t>(n_owned, 1) * 4));
+	HIP_TRY(ctx, ctx->partial.reserve(std::max<size_t>((size_t)n_blocks * n_pad, 1) * 16));
+	HIP_TRY(ctx, ctx->pixels.reserve(std::max<size_t>(n_pad, 1) * 4));
 
 	const bool to_device = p->out_mem == RTA_MEM_DEVICE;
 	float *d_frame = nullptr;
@@ -585,12 +597,16 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	a.thr = ctx->thr.as<float4>();
 	a.col = ctx->col.as<float4>();
 	a.acc = ctx->acc.as<float4>();
+	a.meta = ctx->meta.as<uint4>();
 	a.n_slots = n_slots;
 	a.shadow = ctx->shadow.as<float4>();
 	a.cnt = ctx->counters.as<Counters>();
 	a.partial = ctx->partial.as<float4>();
 	a.pixels = ctx->pixels.as<const int32_t>();
-	a.n_owned = n_owned;
+	a.n_tiles = n_tiles;
+	a.n_pad = n_pad;
+	a.n_blocks = n_blocks;
+	a.run_blocks = run_blocks;
 	a.n_items = n_items;
 	a.spp = spp;
 	a.sps = sps;
@@ -625,11 +641,11 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		}                                                    \
 	} while (0)
 
-	if (n_owned)
-		HIP_TRY_R(hipMemcpyAsync(ctx->pixels.ptr, px.data(), (size_t)n_owned * 4, hipMemcpyHostToDevice, s));
+	if (n_pad)
+		HIP_TRY_R(hipMemcpyAsync(ctx->pixels.ptr, px.data(), (size_t)n_pad * 4, hipMemcpyHostToDevice, s));
 	Counters init;
 	memset(&init, 0, sizeof init);
-	init.live = n_slots;
+	init.live = n_slots / 64;
 	*ctx->host_counters = init;
 	HIP_TRY_R(hipMemcpyAsync(ctx->counters.ptr, ctx->host_counters, sizeof(Counters), hipMemcpyHostToDevice, s));
 	HIP_TRY_R(hipStreamSynchronize(s));       // host_counters is reused for read-back below
@@ -677,11 +693,10 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		done = ctx->host_counters->live == 0;
 	}
 
-	const uint32_t blocks = n_blocks;
 	if (d_frame && n_owned) {
-		launch_sum_blocks(s, a.partial, a.pixels, n_owned, blocks, d_frame);
+		launch_sum_blocks(s, a.partial, a.pixels, n_pad, n_blocks, d_frame);
 		if (d_bgr)
-			launch_resolve(s, d_frame, a.pixels, n_owned, (float)spp, p->exposure, d_bgr);
+			launch_resolve(s, d_frame, a.pixels, n_pad, (float)spp, p->exposure, d_bgr);
 	}
 	HIP_TRY_R(hipEventRecord(ev_end, s));
 	HIP_TRY_R(hipGetLastError());
@@ -696,13 +711,15 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 			h_frame.resize(frame_px * 3);
 			HIP_TRY_R(hipMemcpy(h_frame.data(), d_frame, frame_px * 12, hipMemcpyDeviceToHost));
 			for (int32_t q : px)
-				memcpy(accum + (size_t)q * 3, h_frame.data() + (size_t)q * 3, 12);
+				if (q >= 0)
+					memcpy(accum + (size_t)q * 3, h_frame.data() + (size_t)q * 3, 12);
 		}
 		if (bgr) {
 			h_bgr.resize(frame_px * 3);
 			HIP_TRY_R(hipMemcpy(h_bgr.data(), d_bgr, frame_px * 3, hipMemcpyDeviceToHost));
 			for (int32_t q : px)
-				memcpy(bgr + (size_t)q * 3, h_bgr.data() + (size_t)q * 3, 3);
+				if (q >= 0)
+					memcpy(bgr + (size_t)q * 3, h_bgr.data() + (size_t)q * 3, 3);
 		}
 	}
 
@@ -722,7 +739,8 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	}
 	const Counters &c = *ctx->host_counters;
 	st.samples = (uint64_t)n_owned * spp;
-	st.rays = c.rays;
+	for (int k = 0; k < kRayShards; k++)
+		st.rays += c.ray_shard[k];
 	st.shadow_rays = c.shadow_rays;
 	st.steps = steps;
 	st.inner_visits = c.inner;

@@ -13,11 +13,15 @@
 // followed once by block-sum accumulation and the tone-mapping resolve
 // (src/main.cpp:692-706).
 //
-// A path slot owns one (pixel, sample block) work item at a time and carries
-// its xorshift32 state from sample to sample, so a block's samples are drawn
-// and summed strictly in order; blocks are handed out through one atomic
-// counter.  Results therefore depend only on (seed, pixel, block), never on the
-// schedule.
+// A path slot works through one (pixel, sample block) stream at a time and
+// carries its xorshift32 state from sample to sample, so a block's samples are
+// drawn and summed strictly in order.  Work is handed out per WAVE: the 64
+// slots of a wave take one 8x8 pixel tile and a run of consecutive sample
+// blocks of it, lane l rendering the tile's pixel l; the wave draws its next
+// (tile, block run) from one atomic counter once all its lanes are through.
+// Camera rays of a wave therefore always go through the same tile, which keeps
+// the lanes of the intersect kernel on the same side of the tree.  Results
+// depend only on (seed, pixel, block), never on this schedule.
 //
 // Lane i of every generate/intersect/shade launch works on slot i, so all slot
 // state (six float4 arrays) is read and written fully coalesced, and because a
@@ -36,9 +40,9 @@ namespace rta {
 
 namespace {
 
-constexpr uint32_t kNoItem = 0xffffffffu;
 // slot states kept in the bounce word (ray1.w): a bounce number, or
-constexpr uint32_t kRetired = 0xfffffffeu;     // no work item left for this slot
+constexpr uint32_t kWaiting = 0xfffffffdu;     // through with its blocks; waits for the wave's next tile
+constexpr uint32_t kRetired = 0xfffffffeu;     // no work left for this wave
 constexpr uint32_t kEnded = 0xffffffffu;       // path finished; generate takes over
 
 RTA_DEV float4 f4(V3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
@@ -74,53 +78,83 @@ RTA_DEV void count_flush(Counters *cnt, const WorkCount &wc)
 __global__ __launch_bounds__(kBlock) void k_generate(const RenderArgs a)
 {
 	const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
-	if (slot >= a.n_slots)
+	if (slot >= a.n_slots)        // n_slots is a multiple of 64: whole waves leave together
 		return;
+	const uint32_t lane = threadIdx.x & 63;
 	float4 R1 = a.ray1[slot];
-	if (__float_as_uint(R1.w) != kEnded)
-		return;
-	float4 A = a.acc[slot];
-	float4 C = a.col[slot];
-	uint32_t rng = __float_as_uint(a.thr[slot].w);
-	uint32_t item = __float_as_uint(A.w);
-	uint32_t done = __float_as_uint(C.w);
-	if (item != kNoItem) {
+	uint32_t state = __float_as_uint(R1.w);
+	if (__ballot(state >= kWaiting && state != kRetired) == 0)
+		return;                   // every lane is mid-path or retired: nothing to generate
+
+	uint4 M = a.meta[slot];       // pixel, current block, end of the block run, index in the padded pixel list
+	float4 A = make_float4(0.f, 0.f, 0.f, 0.f);
+	uint32_t rng = 0, done = 0;
+	bool need_ray = false;
+
+	if (state == kEnded) {
 		// the finished sample joins its block sum (src/main.cpp:689)
+		A = a.acc[slot];
+		const float4 C = a.col[slot];
+		rng = __float_as_uint(a.thr[slot].w);
+		done = __float_as_uint(C.w) + 1;
 		A.x += C.x;
 		A.y += C.y;
 		A.z += C.z;
-		done++;
-		const uint32_t block = item / a.n_owned;
-		const uint32_t first = block * a.sps;
+		const uint32_t first = M.y * a.sps;
 		const uint32_t len = a.spp - first < a.sps ? a.spp - first : a.sps;
+		need_ray = true;
 		if (done >= len) {
-			a.partial[item] = make_float4(A.x, A.y, A.z, 0.f);
-			item = kNoItem;
-		}
-	}
-	if (item == kNoItem) {
-		const uint32_t got = atomicAdd(&a.cnt->next_item, 1u);
-		if (got < a.n_items) {
-			item = got;
-			const uint32_t block = item / a.n_owned;
-			const uint32_t pixel = (uint32_t)a.pixels[item - block * a.n_owned];
-			rng = stream_seed(a.seed, pixel, block);
-			A.x = A.y = A.z = 0.f;
+			a.partial[(size_t)M.y * a.n_pad + M.w] = A;
+			A = make_float4(0.f, 0.f, 0.f, 0.f);
 			done = 0;
-		} else {
-			atomicSub(&a.cnt->live, 1u);
+			M.y++;
+			if (M.y >= M.z) {
+				state = kWaiting;
+				need_ray = false;
+			} else {
+				rng = stream_seed(a.seed, M.x, M.y);
+			}
 		}
 	}
-	A.w = __uint_as_float(item);
-	a.acc[slot] = A;
-	if (item == kNoItem) {
-		R1.w = __uint_as_float(kRetired);
-		a.ray1[slot] = R1;
+
+	// the whole wave is through: draw the next (tile, block run)
+	if (__ballot(state == kWaiting) == ~0ull) {
+		uint32_t got = 0;
+		if (lane == 0)
+			got = atomicAdd(&a.cnt->next_item, 1u);
+		got = __shfl(got, 0);
+		if (got < a.n_items) {
+			const uint32_t run = got / a.n_tiles, tile = got - run * a.n_tiles;
+			const uint32_t padded = tile * 64 + lane;
+			const int32_t pixel = a.pixels[padded];
+			if (pixel >= 0) {
+				M.x = (uint32_t)pixel;
+				M.y = run * a.run_blocks;
+				M.z = M.y + a.run_blocks < a.n_blocks ? M.y + a.run_blocks : a.n_blocks;
+				M.w = padded;
+				rng = stream_seed(a.seed, M.x, M.y);
+				A = make_float4(0.f, 0.f, 0.f, 0.f);
+				done = 0;
+				need_ray = true;
+			}
+		} else {
+			state = kRetired;
+			if (lane == 0)
+				atomicSub(&a.cnt->live, 1u);
+		}
+	}
+
+	if (!need_ray) {
+		if (state != __float_as_uint(R1.w)) {
+			R1.w = __uint_as_float(state);
+			a.ray1[slot] = R1;
+		}
 		return;
 	}
-	const uint32_t block = item / a.n_owned;
-	const uint32_t pixel = (uint32_t)a.pixels[item - block * a.n_owned];
-	const uint32_t pu = pixel % a.width, pv = pixel / a.width;
+	a.meta[slot] = M;
+	a.acc[slot] = A;
+
+	const uint32_t pu = M.x % a.width, pv = M.x / a.width;
 	const V3 cam_o = mk(a.cam.origin[0], a.cam.origin[1], a.cam.origin[2]);
 	V3 origin = cam_o;
 	if (a.cam.defocus_angle > 0) {
@@ -163,15 +197,14 @@ __global__ __launch_bounds__(kBlock) void k_intersect(const RenderArgs a, const 
 {
 	extern __shared__ uint32_t lds_stack[];
 	const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
-	if (slot == 0) {
-		// every live slot carries exactly one ray per step
-		a.cnt->rays += a.cnt->live;
+	if (slot == 0)
 		a.cnt->n_shadow = 0;          // nobody reads or appends to it during this launch
-	}
 	WorkCount wc = {0, 0, 0};
+	bool active = false;
 	if (slot < a.n_slots) {
 		const float4 r1 = a.ray1[slot];
-		if (__float_as_uint(r1.w) < kRetired) {
+		active = __float_as_uint(r1.w) < kWaiting;
+		if (active) {
 			const float4 r0 = a.ray0[slot];
 			Ray ray = {mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y)};
 			HitRec h;
@@ -179,6 +212,11 @@ __global__ __launch_bounds__(kBlock) void k_intersect(const RenderArgs a, const 
 			a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
 		}
 	}
+	// rays of this launch, one add per wave into a counter picked by block so
+	// that the adds spread over many addresses
+	const unsigned long long mask = __ballot(active);
+	if ((threadIdx.x & 63) == 0 && mask)
+		atomicAdd(&a.cnt->ray_shard[blockIdx.x % kRayShards], (unsigned long long)__popcll(mask));
 	if (COUNT)
 		count_flush(a.cnt, wc);
 }
@@ -195,7 +233,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(const RenderArgs a)
 	if (slot < a.n_slots)
 		r1 = a.ray1[slot];
 
-	if (__float_as_uint(r1.w) < kRetired) {
+	if (__float_as_uint(r1.w) < kWaiting) {
 		bool alive = false;
 		const float4 r0 = a.ray0[slot];
 		const float4 H = a.hit[slot];
@@ -359,21 +397,25 @@ __global__ __launch_bounds__(kBlock) void k_shadow(const RenderArgs a, const int
 
 // ------------------------------------------------------------------ finish
 
-// Pixel sum = block sums added in block order from zero.
-__global__ __launch_bounds__(kBlock) void k_sum_blocks(const float4 *partial, const int32_t *pixels, uint32_t n_owned,
+// Pixel sum = block sums added in block order from zero.  `pixels` is the
+// padded per-tile list (64 entries per tile, -1 where the tile leaves the frame).
+__global__ __launch_bounds__(kBlock) void k_sum_blocks(const float4 *partial, const int32_t *pixels, uint32_t n_pad,
                                                        uint32_t n_blocks, float *frame)
 {
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-	if (i >= n_owned)
+	if (i >= n_pad)
+		return;
+	const int32_t pixel = pixels[i];
+	if (pixel < 0)
 		return;
 	float x = 0, y = 0, z = 0;
 	for (uint32_t b = 0; b < n_blocks; b++) {
-		const float4 p = partial[(size_t)b * n_owned + i];
+		const float4 p = partial[(size_t)b * n_pad + i];
 		x += p.x;
 		y += p.y;
 		z += p.z;
 	}
-	float *dst = frame + (size_t)pixels[i] * 3;
+	float *dst = frame + (size_t)pixel * 3;
 	dst[0] = x;
 	dst[1] = y;
 	dst[2] = z;
@@ -399,6 +441,8 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const float *frame, const in
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
 	if (i >= n)
 		return;
+	if (pixels && pixels[i] < 0)
+		return;
 	const size_t p = pixels ? (size_t)pixels[i] : (size_t)i;
 	V3 c = mk(frame[p * 3], frame[p * 3 + 1], frame[p * 3 + 2]) / samples;
 	if (c.x < 0 || c.y < 0 || c.z < 0)
@@ -415,10 +459,11 @@ __global__ __launch_bounds__(kBlock) void k_init_slots(const RenderArgs a, uint3
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
 	if (i >= n_slots)
 		return;
-	a.acc[i] = make_float4(0.f, 0.f, 0.f, __uint_as_float(kNoItem));
+	a.acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 	a.col[i] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
 	a.thr[i] = make_float4(1.f, 1.f, 1.f, __uint_as_float(1u));
-	a.ray1[i] = make_float4(0.f, 0.f, 1.f, __uint_as_float(kEnded));
+	a.meta[i] = make_uint4(0u, 0u, 0u, 0u);
+	a.ray1[i] = make_float4(0.f, 0.f, 1.f, __uint_as_float(kWaiting));
 }
 
 // ------------------------------------------------------------------ ray batches
@@ -522,10 +567,10 @@ void launch_shadow(hipStream_t s, const RenderArgs &a, uint32_t bound, int depth
 		hipLaunchKernelGGL(k_shadow<false>, dim3(blocks_for(bound)), dim3(kBlock), stack_bytes(depth), s, a, depth);
 }
 
-void launch_sum_blocks(hipStream_t s, const float4 *partial, const int32_t *pixels, uint32_t n_owned, uint32_t n_blocks,
+void launch_sum_blocks(hipStream_t s, const float4 *partial, const int32_t *pixels, uint32_t n_pad, uint32_t n_blocks,
                        float *frame)
 {
-	hipLaunchKernelGGL(k_sum_blocks, dim3(blocks_for(n_owned)), dim3(kBlock), 0, s, partial, pixels, n_owned, n_blocks,
+	hipLaunchKernelGGL(k_sum_blocks, dim3(blocks_for(n_pad)), dim3(kBlock), 0, s, partial, pixels, n_pad, n_blocks,
 	                   frame);
 }
 

@@ -11,12 +11,15 @@
 namespace rta {
 
 // Device-resident queue lengths and statistics.  One instance per context.
+constexpr int kRayShards = 64;
+
 struct Counters {
 	uint32_t n_shadow;       // pending occlusion queries
-	uint32_t next_item;      // next (pixel, block) work item to hand out
-	uint32_t live;           // slots that still own or may get a work item
+	uint32_t next_item;      // next (tile, block run) to hand to a wave
+	uint32_t live;           // waves that still have or may get work
 	uint32_t pad;
-	unsigned long long rays, shadow_rays;
+	unsigned long long shadow_rays;
+	unsigned long long ray_shard[kRayShards];      // closest-hit queries; the total is their sum
 	unsigned long long inner, tri, sph;     // RTA_RENDER_COUNT_WORK only
 };
 
@@ -41,15 +44,18 @@ struct RenderArgs {
 	float4 *hit;                   // primitive, t, u, v
 	float4 *thr;                   // throughput rgb, rng state
 	float4 *col;                   // path radiance rgb, samples finished in the current block
-	float4 *acc;                   // block sum rgb, work item
+	float4 *acc;                   // block sum rgb
+	uint4 *meta;                   // pixel, current block, end of the block run, index in the padded pixel list
 	uint32_t n_slots;
 	// occlusion queue, 3 per entry: (origin, limit) (direction, slot) (radiance, -)
 	float4 *shadow;
 	Counters *cnt;
 
-	float4 *partial;               // one block sum per work item
-	const int32_t *pixels;         // pixels owned by this shard
-	uint32_t n_owned, n_items;
+	float4 *partial;               // block sums, [block][padded pixel]
+	const int32_t *pixels;         // this shard's pixels, 64 per tile, -1 where a tile leaves the frame
+	uint32_t n_tiles, n_pad;       // n_pad = 64 * n_tiles
+	uint32_t n_blocks, run_blocks; // sample blocks per pixel; blocks a wave takes at once
+	uint32_t n_items;              // n_tiles * ceil(n_blocks / run_blocks)
 	uint32_t spp, sps;
 	uint32_t width;
 	uint32_t seed;
@@ -63,7 +69,7 @@ void launch_generate(hipStream_t s, const RenderArgs &a);
 void launch_intersect(hipStream_t s, const RenderArgs &a, int depth, bool count);
 void launch_shade(hipStream_t s, const RenderArgs &a);
 void launch_shadow(hipStream_t s, const RenderArgs &a, uint32_t bound, int depth, bool count);
-void launch_sum_blocks(hipStream_t s, const float4 *partial, const int32_t *pixels, uint32_t n_owned, uint32_t n_blocks,
+void launch_sum_blocks(hipStream_t s, const float4 *partial, const int32_t *pixels, uint32_t n_pad, uint32_t n_blocks,
                        float *frame);
 void launch_resolve(hipStream_t s, const float *frame, const int32_t *pixels, uint32_t n, float samples, float exposure,
                     uint8_t *bgr);

@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--samples-per-stream", type=int, default=32)
     ap.add_argument("--slots", type=int, default=0)
     ap.add_argument("--run-blocks", type=int, default=0)
+    ap.add_argument("--streams", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--count-work", action="store_true", help="also count node visits / primitive tests (slower)")
     args = ap.parse_args()
@@ -136,7 +137,7 @@ def main():
 
     p = rta.RenderParams(width=width, height=height, samples=spp, exposure=s.exposure, seed=69420,
                          samples_per_stream=args.samples_per_stream, shard_index=rank, shard_count=world,
-                         slots=args.slots, out_mem=rta.MEM_DEVICE, run_blocks=args.run_blocks,
+                         slots=args.slots, out_mem=rta.MEM_DEVICE, run_blocks=args.run_blocks, streams=args.streams,
                          flags=rta.RENDER_TIME_KERNELS | (rta.RENDER_COUNT_WORK if args.count_work else 0))
     p.sky[:] = list(s.sky)
 

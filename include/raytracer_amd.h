@@ -167,6 +167,8 @@ typedef struct {
 	int32_t flags;                /* RTA_RENDER_* */
 	int32_t run_blocks;           /* consecutive sample blocks of a tile a wave takes at once (scheduling
 	                               * only, results do not depend on it); <= 0: library default */
+	int32_t streams;              /* parts the slot pool is cut into, each stepping on its own HIP stream
+	                               * (scheduling only); <= 0: library default, at most 8 */
 } rta_render_params;
 
 enum {

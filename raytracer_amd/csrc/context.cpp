@@ -25,6 +25,7 @@ constexpr uint32_t kLeaf = 0x80000000u;
 constexpr uint32_t kSphereFlag = 1u, kLastFlag = 2u;
 constexpr int kMaxDepth = 64;             // the reference's traversal stack (src/main.cpp:339)
 constexpr int kTile = 8;                  // pixels per tile side; 64 pixels = one wave64
+constexpr int kMaxGroups = 8;             // slot groups = concurrent HIP streams per render
 
 struct DeviceBuffer {
 	void *ptr = nullptr;
@@ -61,7 +62,8 @@ using namespace rta;
 
 struct rta_context {
 	int device = -1;
-	hipStream_t stream = nullptr;
+	hipStream_t stream = nullptr;         // group 0 and everything that is not a wavefront step
+	hipStream_t extra[kMaxGroups - 1] = {};  // the other slot groups
 	std::string error;
 
 	// scene
@@ -75,7 +77,7 @@ struct rta_context {
 	// wavefront workspace
 	DeviceBuffer ray0, ray1, hit, thr, col, acc, meta, shadow, partial, pixels, frame, bgr, counters;
 	DeviceBuffer io_a, io_b, io_c;       // staging for host-pointer calls
-	Counters *host_counters = nullptr;    // pinned
+	Counters *host_counters = nullptr;    // pinned, kMaxGroups entries
 
 	int fail(int code, const std::string &text)
 	{
@@ -130,9 +132,12 @@ int rta_create(int device, rta_context **out)
 	}
 	rta_context *ctx = new rta_context();
 	ctx->device = device;
-	if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
-	    (e = hipHostMalloc((void **)&ctx->host_counters, sizeof(Counters), hipHostMallocDefault)) != hipSuccess ||
-	    (e = ctx->counters.reserve(sizeof(Counters))) != hipSuccess) {
+	e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+	for (int g = 0; g < kMaxGroups - 1 && e == hipSuccess; g++)
+		e = hipStreamCreateWithFlags(&ctx->extra[g], hipStreamNonBlocking);
+	if (e != hipSuccess ||
+	    (e = hipHostMalloc((void **)&ctx->host_counters, sizeof(Counters) * kMaxGroups, hipHostMallocDefault)) != hipSuccess ||
+	    (e = ctx->counters.reserve(sizeof(Counters) * kMaxGroups)) != hipSuccess) {
 		set_global_error(std::string("context set-up: ") + hipGetErrorString(e));
 		rta_destroy(ctx);
 		return RTA_E_DEVICE;
@@ -150,6 +155,11 @@ void rta_destroy(rta_context *ctx)
 		(void)hipStreamSynchronize(ctx->stream);
 		(void)hipStreamDestroy(ctx->stream);
 	}
+	for (hipStream_t x : ctx->extra)
+		if (x) {
+			(void)hipStreamSynchronize(x);
+			(void)hipStreamDestroy(x);
+		}
 	if (ctx->host_counters)
 		(void)hipHostFree(ctx->host_counters);
 	delete ctx;
@@ -544,9 +554,15 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	rta_stats st;
 	memset(&st, 0, sizeof st);
 
-	uint64_t want_slots = p->slots > 0 ? (uint64_t)p->slots : (1u << 21);
-	want_slots = std::min<uint64_t>((want_slots + 63) / 64, std::max<uint64_t>(items64, 1)) * 64;
-	const uint32_t n_slots = (uint32_t)want_slots;
+	// The slot pool: `groups` equal parts of whole workgroups, never more waves
+	// than there are (tile, block run) pairs to hand out.
+	uint64_t want_waves = ((p->slots > 0 ? (uint64_t)p->slots : (1u << 22)) + 63) / 64;
+	want_waves = std::min<uint64_t>(want_waves, std::max<uint64_t>(items64, 1));
+	int groups = p->streams > 0 ? std::min(p->streams, kMaxGroups) : 4;
+	const uint64_t waves_per_block = 256 / 64;
+	uint64_t group_blocks = (want_waves + groups * waves_per_block - 1) / (groups * waves_per_block);
+	const uint32_t group_slots = (uint32_t)(group_blocks * 256);
+	const uint32_t n_slots = group_slots * (uint32_t)groups;
 	if (items64 + n_slots >= 0xffffffffull || (uint64_t)n_blocks * n_pad >= 0xffffffffull)
 		return ctx->fail(RTA_E_LIMIT, "tiles x sample blocks exceeds 2^32; raise samples_per_stream");
 	const uint32_t n_items = (uint32_t)items64;
@@ -584,37 +600,47 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		}
 	}
 
-	RenderArgs a;
-	memset(&a, 0, sizeof a);
-	a.tree = tree_of(ctx);
-	a.shade_prims = ctx->shade_prims.as<const float4>();
-	a.materials = ctx->materials.as<const float4>();
-	a.lights = ctx->lights.as<const float4>();
-	a.n_lights = ctx->n_lights;
-	a.ray0 = ctx->ray0.as<float4>();
-	a.ray1 = ctx->ray1.as<float4>();
-	a.hit = ctx->hit.as<float4>();
-	a.thr = ctx->thr.as<float4>();
-	a.col = ctx->col.as<float4>();
-	a.acc = ctx->acc.as<float4>();
-	a.meta = ctx->meta.as<uint4>();
-	a.n_slots = n_slots;
-	a.shadow = ctx->shadow.as<float4>();
-	a.cnt = ctx->counters.as<Counters>();
-	a.partial = ctx->partial.as<float4>();
-	a.pixels = ctx->pixels.as<const int32_t>();
-	a.n_tiles = n_tiles;
-	a.n_pad = n_pad;
-	a.n_blocks = n_blocks;
-	a.run_blocks = run_blocks;
-	a.n_items = n_items;
-	a.spp = spp;
-	a.sps = sps;
-	a.width = (uint32_t)p->width;
-	a.seed = p->seed;
-	a.max_bounces = p->max_bounces > 0 ? p->max_bounces : 10;
-	memcpy(a.sky, p->sky, sizeof a.sky);
-	a.cam = *camera;
+	RenderArgs base;
+	memset(&base, 0, sizeof base);
+	base.tree = tree_of(ctx);
+	base.shade_prims = ctx->shade_prims.as<const float4>();
+	base.materials = ctx->materials.as<const float4>();
+	base.lights = ctx->lights.as<const float4>();
+	base.n_lights = ctx->n_lights;
+	base.n_slots = group_slots;
+	base.next_item = &ctx->counters.as<Counters>()[0].next_item;
+	base.partial = ctx->partial.as<float4>();
+	base.pixels = ctx->pixels.as<const int32_t>();
+	base.n_tiles = n_tiles;
+	base.n_pad = n_pad;
+	base.n_blocks = n_blocks;
+	base.run_blocks = run_blocks;
+	base.n_items = n_items;
+	base.spp = spp;
+	base.sps = sps;
+	base.width = (uint32_t)p->width;
+	base.seed = p->seed;
+	base.max_bounces = p->max_bounces > 0 ? p->max_bounces : 10;
+	memcpy(base.sky, p->sky, sizeof base.sky);
+	base.cam = *camera;
+
+	// one RenderArgs and one stream per slot group
+	std::vector<RenderArgs> ga((size_t)groups, base);
+	std::vector<hipStream_t> gs((size_t)groups);
+	for (int g = 0; g < groups; g++) {
+		const size_t off = (size_t)g * group_slots;
+		RenderArgs &a = ga[g];
+		a.ray0 = ctx->ray0.as<float4>() + off;
+		a.ray1 = ctx->ray1.as<float4>() + off;
+		a.hit = ctx->hit.as<float4>() + off;
+		a.thr = ctx->thr.as<float4>() + off;
+		a.col = ctx->col.as<float4>() + off;
+		a.acc = ctx->acc.as<float4>() + off;
+		a.meta = ctx->meta.as<uint4>() + off;
+		a.shadow = ctx->shadow.as<float4>() ? ctx->shadow.as<float4>() + 3 * off : nullptr;
+		a.cnt = ctx->counters.as<Counters>() + g;
+		gs[g] = g == 0 ? ctx->stream : ctx->extra[g - 1];
+	}
 
 	const bool time_kernels = (p->flags & RTA_RENDER_TIME_KERNELS) != 0;
 	const bool count_work = (p->flags & RTA_RENDER_COUNT_WORK) != 0;
@@ -624,7 +650,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	hipEvent_t ev_begin = nullptr, ev_end = nullptr;
 	HIP_TRY(ctx, hipEventCreate(&ev_begin));
 	HIP_TRY(ctx, hipEventCreate(&ev_end));
-	std::vector<hipEvent_t> ev_pool;        // begin/end pairs around timed launches
+	std::vector<hipEvent_t> ev_pool;        // begin/end pairs around timed launches, then the per-group end marks
 	std::vector<int> ev_kind;               // 0 intersect, 1 shadow
 	auto cleanup = [&]() {
 		(void)hipEventDestroy(ev_begin);
@@ -643,23 +669,27 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 
 	if (n_pad)
 		HIP_TRY_R(hipMemcpyAsync(ctx->pixels.ptr, px.data(), (size_t)n_pad * 4, hipMemcpyHostToDevice, s));
-	Counters init;
-	memset(&init, 0, sizeof init);
-	init.live = n_slots / 64;
-	*ctx->host_counters = init;
-	HIP_TRY_R(hipMemcpyAsync(ctx->counters.ptr, ctx->host_counters, sizeof(Counters), hipMemcpyHostToDevice, s));
+	for (int g = 0; g < kMaxGroups; g++) {
+		memset(&ctx->host_counters[g], 0, sizeof(Counters));
+		ctx->host_counters[g].live = g < groups ? group_slots / 64 : 0;
+	}
+	HIP_TRY_R(hipMemcpyAsync(ctx->counters.ptr, ctx->host_counters, sizeof(Counters) * kMaxGroups, hipMemcpyHostToDevice, s));
 	HIP_TRY_R(hipStreamSynchronize(s));       // host_counters is reused for read-back below
 
 	HIP_TRY_R(hipEventRecord(ev_begin, s));
-	launch_init_slots(s, a, n_slots);
+	for (int g = 1; g < groups; g++)
+		HIP_TRY_R(hipStreamWaitEvent(gs[g], ev_begin, 0));
+	for (int g = 0; g < groups; g++)
+		launch_init_slots(gs[g], ga[g], group_slots);
 
 	// The wavefront loop.  Progress lives on the device; the host reads it back
 	// every `poll` steps only to notice the end (steps past the end find every
-	// slot retired and do nothing).
+	// slot retired and do nothing).  The groups' steps are issued round-robin on
+	// their own streams and run concurrently.
 	const int poll = 16;
 	uint64_t steps = 0;
 	bool done = n_items == 0;
-	auto timed = [&](int kind, auto &&launch) -> hipError_t {
+	auto timed = [&](hipStream_t st_, int kind, auto &&launch) -> hipError_t {
 		if (!time_kernels) {
 			launch();
 			return hipSuccess;
@@ -673,34 +703,42 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 			return e;
 		ev_pool.push_back(e1);
 		ev_kind.push_back(kind);
-		if ((e = hipEventRecord(e0, s)) != hipSuccess)
+		if ((e = hipEventRecord(e0, st_)) != hipSuccess)
 			return e;
 		launch();
-		return hipEventRecord(e1, s);
+		return hipEventRecord(e1, st_);
 	};
 	while (!done) {
 		for (int k = 0; k < poll; k++) {
-			launch_generate(s, a);
-			HIP_TRY_R(timed(0, [&] { launch_intersect(s, a, ctx->stack_depth, count_work); }));
-			launch_shade(s, a);
-			if (lights)
-				HIP_TRY_R(timed(1, [&] { launch_shadow(s, a, n_slots, ctx->stack_depth, count_work); }));
+			for (int g = 0; g < groups; g++) {
+				const RenderArgs &a = ga[g];
+				launch_generate(gs[g], a);
+				HIP_TRY_R(timed(gs[g], 0, [&] { launch_intersect(gs[g], a, ctx->stack_depth, count_work); }));
+				launch_shade(gs[g], a);
+				if (lights)
+					HIP_TRY_R(timed(gs[g], 1, [&] { launch_shadow(gs[g], a, group_slots, ctx->stack_depth, count_work); }));
+			}
 			steps++;
 		}
 		HIP_TRY_R(hipGetLastError());
-		HIP_TRY_R(hipMemcpyAsync(ctx->host_counters, ctx->counters.ptr, sizeof(Counters), hipMemcpyDeviceToHost, s));
-		HIP_TRY_R(hipStreamSynchronize(s));
-		done = ctx->host_counters->live == 0;
+		for (int g = 0; g < groups; g++)
+			HIP_TRY_R(hipMemcpyAsync(&ctx->host_counters[g], ctx->counters.as<Counters>() + g, sizeof(Counters),
+			                         hipMemcpyDeviceToHost, gs[g]));
+		done = true;
+		for (int g = 0; g < groups; g++) {
+			HIP_TRY_R(hipStreamSynchronize(gs[g]));
+			done = done && ctx->host_counters[g].live == 0;
+		}
 	}
 
+	// all groups are idle here (synchronised above)
 	if (d_frame && n_owned) {
-		launch_sum_blocks(s, a.partial, a.pixels, n_pad, n_blocks, d_frame);
+		launch_sum_blocks(s, base.partial, base.pixels, n_pad, n_blocks, d_frame);
 		if (d_bgr)
-			launch_resolve(s, d_frame, a.pixels, n_pad, (float)spp, p->exposure, d_bgr);
+			launch_resolve(s, d_frame, base.pixels, n_pad, (float)spp, p->exposure, d_bgr);
 	}
 	HIP_TRY_R(hipEventRecord(ev_end, s));
 	HIP_TRY_R(hipGetLastError());
-	HIP_TRY_R(hipMemcpyAsync(ctx->host_counters, ctx->counters.ptr, sizeof(Counters), hipMemcpyDeviceToHost, s));
 	HIP_TRY_R(hipStreamSynchronize(s));
 
 	if (!to_device && n_owned) {
@@ -737,15 +775,17 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 			st.shadow_launches++;
 		}
 	}
-	const Counters &c = *ctx->host_counters;
 	st.samples = (uint64_t)n_owned * spp;
-	for (int k = 0; k < kRayShards; k++)
-		st.rays += c.ray_shard[k];
-	st.shadow_rays = c.shadow_rays;
+	for (int g = 0; g < groups; g++) {
+		const Counters &c = ctx->host_counters[g];
+		for (int k = 0; k < kRayShards; k++)
+			st.rays += c.ray_shard[k];
+		st.shadow_rays += c.shadow_rays;
+		st.inner_visits += c.inner;
+		st.tri_tests += c.tri;
+		st.sph_tests += c.sph;
+	}
 	st.steps = steps;
-	st.inner_visits = c.inner;
-	st.tri_tests = c.tri;
-	st.sph_tests = c.sph;
 	if (stats)
 		*stats = st;
 	cleanup();

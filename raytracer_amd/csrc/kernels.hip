@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(const RenderArgs a)
 	if (__ballot(state == kWaiting) == ~0ull) {
 		uint32_t got = 0;
 		if (lane == 0)
-			got = atomicAdd(&a.cnt->next_item, 1u);
+			got = atomicAdd(a.next_item, 1u);
 		got = __shfl(got, 0);
 		if (got < a.n_items) {
 			const uint32_t run = got / a.n_tiles, tile = got - run * a.n_tiles;
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect(const RenderArgs a, const 
 			const float4 r0 = a.ray0[slot];
 			Ray ray = {mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y)};
 			HitRec h;
-			traverse_dyn<false, COUNT>(a.tree, ray, FLT_MAX, lds_stack + threadIdx.x, depth, a.tree.tame != 0, h, wc);
+			traverse_dyn<false, COUNT>(a.tree, ray, FLT_MAX, lds_stack + threadIdx.x, depth, h, wc);
 			a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
 		}
 	}
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow(const RenderArgs a, const int
 		const float4 e0 = e[0], e1 = e[1], e2 = e[2];
 		Ray ray = {xyz(e0), xyz(e1)};
 		HitRec h;
-		traverse_dyn<true, COUNT>(a.tree, ray, e0.w, lds_stack + threadIdx.x, depth, a.tree.tame != 0, h, wc);
+		traverse_dyn<true, COUNT>(a.tree, ray, e0.w, lds_stack + threadIdx.x, depth, h, wc);
 		if (h.prim < 0) {
 			// src/main.cpp:569: the light's contribution joins the path radiance
 			const uint32_t slot = __float_as_uint(e1.w);
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(kBlock) void k_batch_closest(const DeviceTree tree,
 		const float *r = rays + i * 6;
 		Ray ray = {mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5])};
 		HitRec h;
-		traverse_dyn<false, COUNT>(tree, ray, FLT_MAX, lds_stack + threadIdx.x, depth, tree.tame != 0, h, wc);
+		traverse_dyn<false, COUNT>(tree, ray, FLT_MAX, lds_stack + threadIdx.x, depth, h, wc);
 		rta_hit out;
 		out.prim = h.prim;
 		out.t = h.t;
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(kBlock) void k_batch_occluded(const DeviceTree tree
 	Ray ray = {mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5])};
 	HitRec h;
 	WorkCount wc = {0, 0, 0};
-	traverse_dyn<true, false>(tree, ray, tmax[i], lds_stack + threadIdx.x, depth, tree.tame != 0, h, wc);
+	traverse_dyn<true, false>(tree, ray, tmax[i], lds_stack + threadIdx.x, depth, h, wc);
 	out[i] = h.prim >= 0 ? 1 : 0;
 }
 

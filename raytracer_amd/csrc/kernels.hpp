@@ -10,12 +10,12 @@
 
 namespace rta {
 
-// Device-resident queue lengths and statistics.  One instance per context.
 constexpr int kRayShards = 64;
 
+// Device-resident progress and statistics of one slot group (see RenderArgs).
 struct Counters {
 	uint32_t n_shadow;       // pending occlusion queries
-	uint32_t next_item;      // next (tile, block run) to hand to a wave
+	uint32_t next_item;      // next (tile, block run) to hand to a wave; only group 0's is used
 	uint32_t live;           // waves that still have or may get work
 	uint32_t pad;
 	unsigned long long shadow_rays;
@@ -30,7 +30,10 @@ struct TreeRef {
 	uint32_t tame;           // every box coordinate is 0 or within [2^-78, 2^40] in magnitude
 };
 
-// Everything a wavefront kernel needs, passed by value.
+// Everything a wavefront kernel needs, passed by value.  The slot pool is cut
+// into groups that run their wavefront steps on different HIP streams, so that
+// one group's kernels fill the GPU while another group's kernel drains its last
+// long rays; a RenderArgs describes one group (pointers already offset to it).
 struct RenderArgs {
 	TreeRef tree;
 	const float4 *shade_prims;     // 3 per primitive: (n0, material) (n1, light) (n2, type)
@@ -49,7 +52,8 @@ struct RenderArgs {
 	uint32_t n_slots;
 	// occlusion queue, 3 per entry: (origin, limit) (direction, slot) (radiance, -)
 	float4 *shadow;
-	Counters *cnt;
+	Counters *cnt;                 // this group's
+	uint32_t *next_item;           // shared by all groups
 
 	float4 *partial;               // block sums, [block][padded pixel]
 	const int32_t *pixels;         // this shard's pixels, 64 per tile, -1 where a tile leaves the frame

@@ -168,31 +168,46 @@ RTA_DEV float test_box_tame(V3 lo, V3 hi, const Ray &r, V3 rcp, RaySigns s, floa
 }
 
 // Traversal of src/main.cpp:332-422 (closest, ANY = false) and :424-478 (any
-// hit, ANY = true).  `stack` points at this lane's column of an LDS array laid
-// out [depth][kBlock], so consecutive lanes hit consecutive banks.  `depth` is
-// the number of entries the column has (the launch sizes dynamic LDS from it);
-// upload guarantees the tree never needs more.  For ANY, `limit` is the
-// distance bound and the result is hit.prim >= 0.
+// hit, ANY = true), kept as an explicit per-lane state machine so that a kernel
+// can interleave the two phases of many rays and swap finished rays for new
+// ones between phases:
 //
-// The loop is split in two phases so that a wave64 spends its time converged:
-// every lane first descends inner nodes until it holds a leaf (or runs out of
-// work), then the lanes holding leaves test primitives together.
+//   descend()  walks inner nodes until the lane holds a leaf or is finished
+//   leaf()     tests the leaf's primitives, then pops the next pending node
+//
+// `stack` points at the lane's column of an LDS array laid out [depth][kBlock],
+// so consecutive lanes hit consecutive banks; upload guarantees the tree never
+// needs more than `depth` entries.  For ANY, `limit` is the distance bound and
+// the answer is prim >= 0.
 template <bool ANY, bool COUNT>
-RTA_DEV void traverse_dyn(const DeviceTree &tree, const Ray &ray, float limit, uint32_t *stack, const int depth,
-                          const bool scene_tame, HitRec &hit, WorkCount &work)
-{
-	const RaySigns sg = signs_of(ray);
-	const bool tame = scene_tame && ray_is_tame(ray);
-	// correctly rounded reciprocals; garbage (unused) for rays that are not tame
-	const V3 rcp = mk(1.f / ray.d.x, 1.f / ray.d.y, 1.f / ray.d.z);
-	float best = ANY ? limit : FLT_MAX;
-	int32_t best_prim = -1;
-	float best_u = 0, best_v = 0;
-	uint32_t node = tree.root;
-	int sp = 0;
-	bool more = true;
+struct Traversal {
+	Ray ray;
+	V3 rcp;              // correctly rounded 1/direction (only used when tame)
+	RaySigns sg;
+	bool tame;
+	bool more;           // false once the answer is final
+	float best;
+	int32_t prim;
+	float u, v;
+	uint32_t node;
+	int sp;
 
-	while (more) {
+	RTA_DEV void start(const DeviceTree &tree, const Ray &r, float limit)
+	{
+		ray = r;
+		sg = signs_of(r);
+		tame = tree.tame != 0 && ray_is_tame(r);
+		rcp = mk(1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z);
+		best = ANY ? limit : FLT_MAX;
+		prim = -1;
+		u = v = 0.f;
+		node = tree.root;
+		sp = 0;
+		more = true;
+	}
+
+	RTA_DEV void descend(const DeviceTree &tree, uint32_t *stack, const int depth, WorkCount &work)
+	{
 		while (more && !(node & kLeafBit)) {
 			if (COUNT) work.inner++;
 			const float4 *rec = tree.pairs + 4 * (size_t)node;
@@ -237,48 +252,67 @@ RTA_DEV void traverse_dyn(const DeviceTree &tree, const Ray &ray, float limit, u
 				more = false;
 			}
 		}
-		if (!more)
-			break;
+	}
 
+	// Precondition: more && (node & kLeafBit)
+	RTA_DEV void leaf(const DeviceTree &tree, uint32_t *stack, WorkCount &work)
+	{
 		uint32_t i = node & ~kLeafBit;
 		for (;;) {
 			const float4 p0 = tree.prims[3 * (size_t)i];
 			const float4 p1 = tree.prims[3 * (size_t)i + 1];
 			const uint32_t flags = __float_as_uint(p0.w);
-			float t, u = 0, v = 0;
+			float t, tu = 0, tv = 0;
 			if (flags & kPrimSphere) {
 				if (COUNT) work.sph++;
 				t = test_sphere(mk(p0.x, p0.y, p0.z), p1.x, ray);
 			} else {
 				if (COUNT) work.tri++;
 				const float4 p2 = tree.prims[3 * (size_t)i + 2];
-				t = test_triangle(mk(p0.x, p0.y, p0.z), mk(p1.x, p1.y, p1.z), mk(p2.x, p2.y, p2.z), ray, u, v);
+				t = test_triangle(mk(p0.x, p0.y, p0.z), mk(p1.x, p1.y, p1.z), mk(p2.x, p2.y, p2.z), ray, tu, tv);
 			}
 			if (t < best) {           // strict: the first-visited primitive keeps a tie
-				best_prim = (int32_t)i;
+				prim = (int32_t)i;
 				if (ANY) {
 					more = false;
-					break;
+					return;
 				}
 				best = t;
-				best_u = u;
-				best_v = v;
+				u = tu;
+				v = tv;
 			}
 			if (flags & kPrimLast)
 				break;
 			i++;
 		}
-		if (more) {
-			if (sp > 0)
-				node = stack[(--sp) * kBlock];
-			else
-				more = false;
-		}
+		if (sp > 0)
+			node = stack[(--sp) * kBlock];
+		else
+			more = false;
 	}
-	hit.prim = best_prim;
-	hit.t = ANY ? 0.f : best;
-	hit.u = best_u;
-	hit.v = best_v;
+
+	RTA_DEV HitRec result() const { return HitRec{prim, ANY ? 0.f : best, u, v}; }
+};
+
+// One ray per lane from start to finish.  The two phases alternate so that a
+// wave64 spends its time converged: every lane first descends until it holds a
+// leaf (or runs out of work), then the lanes holding leaves test primitives
+// together.
+template <bool ANY, bool COUNT>
+RTA_DEV void traverse_dyn(const DeviceTree &tree, const Ray &ray, float limit, uint32_t *stack, const int depth,
+                          HitRec &hit, WorkCount &work)
+{
+	Traversal<ANY, COUNT> tr;
+	tr.start(tree, ray, limit);
+	for (;;) {
+		tr.descend(tree, stack, depth, work);
+		if (!tr.more)
+			break;
+		tr.leaf(tree, stack, work);
+		if (!tr.more)
+			break;
+	}
+	hit = tr.result();
 }
 
 }  // namespace rta

@@ -75,7 +75,7 @@ struct rta_context {
 	int32_t n_prims = 0, n_lights = 0;
 
 	// wavefront workspace
-	DeviceBuffer ray0, ray1, hit, thr, col, acc, meta, shadow, partial, pixels, frame, bgr, counters;
+	DeviceBuffer ray0, ray1, hit, thr, col, acc, meta, q_ray, shadow, partial, pixels, frame, bgr, counters;
 	DeviceBuffer io_a, io_b, io_c;       // staging for host-pointer calls
 	Counters *host_counters = nullptr;    // pinned, kMaxGroups entries
 
@@ -576,6 +576,11 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	HIP_TRY(ctx, ctx->col.reserve(S * 16));
 	HIP_TRY(ctx, ctx->acc.reserve(S * 16));
 	HIP_TRY(ctx, ctx->meta.reserve(S * 16));
+	// per group: 2 parities x 2 kinds x kShards sub-queues, each able to take
+	// everything its share of the group's workgroups can append in one launch
+	const uint32_t shard_cap = (uint32_t)((group_blocks + kShards - 1) / kShards) * 256;
+	const size_t group_queue = (size_t)4 * kShards * shard_cap;
+	HIP_TRY(ctx, ctx->q_ray.reserve(group_queue * groups * 4));
 	if (ctx->n_lights > 0)
 		HIP_TRY(ctx, ctx->shadow.reserve(S * 48));
 	HIP_TRY(ctx, ctx->partial.reserve(std::max<size_t>((size_t)n_blocks * n_pad, 1) * 16));
@@ -638,6 +643,8 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		a.acc = ctx->acc.as<float4>() + off;
 		a.meta = ctx->meta.as<uint4>() + off;
 		a.shadow = ctx->shadow.as<float4>() ? ctx->shadow.as<float4>() + 3 * off : nullptr;
+		a.q_ray = ctx->q_ray.as<uint32_t>() + (size_t)g * group_queue;
+		a.shard_cap = shard_cap;
 		a.cnt = ctx->counters.as<Counters>() + g;
 		gs[g] = g == 0 ? ctx->stream : ctx->extra[g - 1];
 	}
@@ -712,9 +719,10 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		for (int k = 0; k < poll; k++) {
 			for (int g = 0; g < groups; g++) {
 				const RenderArgs &a = ga[g];
-				launch_generate(gs[g], a);
-				HIP_TRY_R(timed(gs[g], 0, [&] { launch_intersect(gs[g], a, ctx->stack_depth, count_work); }));
-				launch_shade(gs[g], a);
+				const int par = (int)(steps & 1);
+				launch_generate(gs[g], a, par);
+				HIP_TRY_R(timed(gs[g], 0, [&] { launch_intersect(gs[g], a, par, ctx->stack_depth, count_work); }));
+				launch_shade(gs[g], a, par ^ 1);
 				if (lights)
 					HIP_TRY_R(timed(gs[g], 1, [&] { launch_shadow(gs[g], a, group_slots, ctx->stack_depth, count_work); }));
 			}
@@ -778,8 +786,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	st.samples = (uint64_t)n_owned * spp;
 	for (int g = 0; g < groups; g++) {
 		const Counters &c = ctx->host_counters[g];
-		for (int k = 0; k < kRayShards; k++)
-			st.rays += c.ray_shard[k];
+		st.rays += c.rays;
 		st.shadow_rays += c.shadow_rays;
 		st.inner_visits += c.inner;
 		st.tri_tests += c.tri;

@@ -23,13 +23,17 @@
 // the lanes of the intersect kernel on the same side of the tree.  Results
 // depend only on (seed, pixel, block), never on this schedule.
 //
-// Lane i of every generate/intersect/shade launch works on slot i, so all slot
-// state (six float4 arrays) is read and written fully coalesced, and because a
-// finished path is replaced in place by its block's next camera sample every
-// live slot carries exactly one ray per step: the closest-hit "queue" is the
-// slot array itself and never has holes until the work items run out.  The
-// occlusion queries, which only some lanes issue, do go through a queue that is
-// compacted with a wave64 ballot + prefix count and one atomic per wave.
+// Lane i of every generate and shade launch works on slot i, so the slot state
+// (seven 16-byte arrays) is read and written fully coalesced.  Rays reach the
+// traversal kernels through queues compacted with a wave64 ballot + prefix
+// count and one atomic per wave: generate queues the slots of fresh camera rays
+// (coherent: a wave's rays cross one tile), shade queues the slots of
+// continuing paths (incoherent bounce rays) separately, and queues occlusion
+// queries with their payload.  Keeping the two kinds of closest-hit rays in
+// different queues is the divergence control: a traversal wave then holds rays
+// of one kind, whose node-visit counts differ far less than across kinds.  Each
+// queue is cut into kShards sub-queues (picked by workgroup) so that the
+// appending atomics spread over many addresses.
 
 #include "kernels.hpp"
 
@@ -44,6 +48,8 @@ namespace {
 constexpr uint32_t kWaiting = 0xfffffffdu;     // through with its blocks; waits for the wave's next tile
 constexpr uint32_t kRetired = 0xfffffffeu;     // no work left for this wave
 constexpr uint32_t kEnded = 0xffffffffu;       // path finished; generate takes over
+// kinds of closest-hit rays, queued apart
+constexpr int kCameraRays = 0, kBounceRays = 1;
 
 RTA_DEV float4 f4(V3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
 RTA_DEV float4 f4u(V3 v, uint32_t w) { return make_float4(v.x, v.y, v.z, __uint_as_float(w)); }
@@ -73,9 +79,24 @@ RTA_DEV void count_flush(Counters *cnt, const WorkCount &wc)
 	if (wc.sph) atomicAdd(&cnt->sph, (unsigned long long)wc.sph);
 }
 
+// The closest-hit ray queues: [step parity][kind][shard][capacity] slot numbers,
+// lengths in Counters::n_ray in the same order.
+RTA_DEV uint32_t ray_queue_index(int par, int kind, uint32_t shard) { return ((uint32_t)par * 2 + (uint32_t)kind) * kShards + shard; }
+
+RTA_DEV void ray_queue_push(const RenderArgs &a, int par, int kind, bool pred, uint32_t slot)
+{
+	const uint32_t q = ray_queue_index(par, kind, blockIdx.x % kShards);
+	const uint32_t at = queue_push(pred, &a.cnt->n_ray[q]);
+	if (pred)
+		a.q_ray[(size_t)q * a.shard_cap + at] = slot;
+}
+
 // ------------------------------------------------------------------ generate
 
-__global__ __launch_bounds__(kBlock) void k_generate(const RenderArgs a)
+RTA_DEV void camera_ray(const RenderArgs &a, uint32_t slot, uint32_t pixel, uint32_t rng, uint32_t done);
+
+// `par`: parity of the step whose intersect launch will trace the new rays.
+__global__ __launch_bounds__(kBlock) void k_generate(const RenderArgs a, const int par)
 {
 	const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
 	if (slot >= a.n_slots)        // n_slots is a multiple of 64: whole waves leave together
@@ -149,12 +170,18 @@ __global__ __launch_bounds__(kBlock) void k_generate(const RenderArgs a)
 			R1.w = __uint_as_float(state);
 			a.ray1[slot] = R1;
 		}
-		return;
+	} else {
+		a.meta[slot] = M;
+		a.acc[slot] = A;
+		camera_ray(a, slot, M.x, rng, done);
 	}
-	a.meta[slot] = M;
-	a.acc[slot] = A;
+	ray_queue_push(a, par, kCameraRays, need_ray, slot);
+}
 
-	const uint32_t pu = M.x % a.width, pv = M.x / a.width;
+// One camera sample of pixel `pixel` (src/main.cpp:663-687) written into `slot`.
+RTA_DEV void camera_ray(const RenderArgs &a, uint32_t slot, uint32_t pixel, uint32_t rng, uint32_t done)
+{
+	const uint32_t pu = pixel % a.width, pv = pixel / a.width;
 	const V3 cam_o = mk(a.cam.origin[0], a.cam.origin[1], a.cam.origin[2]);
 	V3 origin = cam_o;
 	if (a.cam.defocus_angle > 0) {
@@ -192,41 +219,51 @@ __global__ __launch_bounds__(kBlock) void k_generate(const RenderArgs a)
 
 // ------------------------------------------------------------------ intersect
 
+// Grid: 2 kinds x kShards sub-queues x (shard_cap / kBlock) workgroups, shards
+// innermost so that the first workgroups of all shards start together; a
+// workgroup whose part of its sub-queue is empty leaves at once.
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_intersect(const RenderArgs a, const int depth)
+__global__ __launch_bounds__(kBlock) void k_intersect(const RenderArgs a, const int par, const int depth)
 {
 	extern __shared__ uint32_t lds_stack[];
-	const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
-	if (slot == 0)
-		a.cnt->n_shadow = 0;          // nobody reads or appends to it during this launch
-	WorkCount wc = {0, 0, 0};
-	bool active = false;
-	if (slot < a.n_slots) {
-		const float4 r1 = a.ray1[slot];
-		active = __float_as_uint(r1.w) < kWaiting;
-		if (active) {
-			const float4 r0 = a.ray0[slot];
-			Ray ray = {mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y)};
-			HitRec h;
-			traverse_dyn<false, COUNT>(a.tree, ray, FLT_MAX, lds_stack + threadIdx.x, depth, h, wc);
-			a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
+	const uint32_t per_kind = kShards * (a.shard_cap / kBlock);
+	const uint32_t kind = blockIdx.x / per_kind, rem = blockIdx.x - kind * per_kind;
+	const uint32_t shard = rem % kShards, part = rem / kShards;
+	const uint32_t q = ray_queue_index(par, (int)kind, shard);
+	const uint32_t total = a.cnt->n_ray[q];
+	if (blockIdx.x == 0) {
+		// housekeeping by the first workgroup: count this launch's rays, empty the
+		// queues the previous launch consumed, empty the occlusion queue
+		if (threadIdx.x < 2 * kShards) {
+			const uint32_t n = a.cnt->n_ray[ray_queue_index(par, 0, 0) + threadIdx.x];
+			if (n)
+				atomicAdd(&a.cnt->rays, (unsigned long long)n);
+			a.cnt->n_ray[ray_queue_index(par ^ 1, 0, 0) + threadIdx.x] = 0;
 		}
+		if (threadIdx.x == 0)
+			a.cnt->n_shadow = 0;
 	}
-	// rays of this launch, one add per wave into a counter picked by block so
-	// that the adds spread over many addresses
-	const unsigned long long mask = __ballot(active);
-	if ((threadIdx.x & 63) == 0 && mask)
-		atomicAdd(&a.cnt->ray_shard[blockIdx.x % kRayShards], (unsigned long long)__popcll(mask));
+	const uint32_t i = part * kBlock + threadIdx.x;
+	WorkCount wc = {0, 0, 0};
+	if (i < total) {
+		const uint32_t slot = a.q_ray[(size_t)q * a.shard_cap + i];
+		const float4 r0 = a.ray0[slot], r1 = a.ray1[slot];
+		Ray ray = {mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y)};
+		HitRec h;
+		traverse_dyn<false, COUNT>(a.tree, ray, FLT_MAX, lds_stack + threadIdx.x, depth, h, wc);
+		a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
+	}
 	if (COUNT)
 		count_flush(a.cnt, wc);
 }
 
 // ------------------------------------------------------------------ shade
 
-__global__ __launch_bounds__(kBlock) void k_shade(const RenderArgs a)
+// `par`: parity of the NEXT step, whose intersect launch traces the bounce rays.
+__global__ __launch_bounds__(kBlock) void k_shade(const RenderArgs a, const int par)
 {
 	const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
-	bool want_shadow = false;
+	bool want_shadow = false, alive = false;
 	V3 sh_o = mk(0, 0, 0), sh_d = mk(0, 0, 0), sh_c = mk(0, 0, 0);
 	float sh_dist = 0;
 	float4 r1 = make_float4(0.f, 0.f, 0.f, __uint_as_float(kRetired));
@@ -234,7 +271,6 @@ __global__ __launch_bounds__(kBlock) void k_shade(const RenderArgs a)
 		r1 = a.ray1[slot];
 
 	if (__float_as_uint(r1.w) < kWaiting) {
-		bool alive = false;
 		const float4 r0 = a.ray0[slot];
 		const float4 H = a.hit[slot];
 		float4 T = a.thr[slot];
@@ -353,6 +389,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(const RenderArgs a)
 		a.col[slot] = make_float4(color.x, color.y, color.z, C.w);
 	}
 
+	ray_queue_push(a, par, kBounceRays, alive, slot);
 	if (a.n_lights > 0) {
 		const uint32_t at_sh = queue_push(want_shadow, &a.cnt->n_shadow);
 		if (want_shadow) {
@@ -539,24 +576,23 @@ void launch_init_slots(hipStream_t s, const RenderArgs &a, uint32_t n_slots)
 	hipLaunchKernelGGL(k_init_slots, dim3(blocks_for(n_slots)), dim3(kBlock), 0, s, a, n_slots);
 }
 
-void launch_generate(hipStream_t s, const RenderArgs &a)
+void launch_generate(hipStream_t s, const RenderArgs &a, int par)
 {
-	hipLaunchKernelGGL(k_generate, dim3(blocks_for(a.n_slots)), dim3(kBlock), 0, s, a);
+	hipLaunchKernelGGL(k_generate, dim3(blocks_for(a.n_slots)), dim3(kBlock), 0, s, a, par);
 }
 
-void launch_intersect(hipStream_t s, const RenderArgs &a, int depth, bool count)
+void launch_intersect(hipStream_t s, const RenderArgs &a, int par, int depth, bool count)
 {
+	const unsigned blocks = 2 * kShards * (a.shard_cap / kBlock);
 	if (count)
-		hipLaunchKernelGGL(k_intersect<true>, dim3(blocks_for(a.n_slots)), dim3(kBlock), stack_bytes(depth), s, a,
-		                   depth);
+		hipLaunchKernelGGL(k_intersect<true>, dim3(blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);
 	else
-		hipLaunchKernelGGL(k_intersect<false>, dim3(blocks_for(a.n_slots)), dim3(kBlock), stack_bytes(depth), s, a,
-		                   depth);
+		hipLaunchKernelGGL(k_intersect<false>, dim3(blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);
 }
 
-void launch_shade(hipStream_t s, const RenderArgs &a)
+void launch_shade(hipStream_t s, const RenderArgs &a, int par)
 {
-	hipLaunchKernelGGL(k_shade, dim3(blocks_for(a.n_slots)), dim3(kBlock), 0, s, a);
+	hipLaunchKernelGGL(k_shade, dim3(blocks_for(a.n_slots)), dim3(kBlock), 0, s, a, par);
 }
 
 void launch_shadow(hipStream_t s, const RenderArgs &a, uint32_t bound, int depth, bool count)

@@ -10,7 +10,7 @@
 
 namespace rta {
 
-constexpr int kRayShards = 64;
+constexpr uint32_t kShards = 64;      // sub-queues per ray queue
 
 // Device-resident progress and statistics of one slot group (see RenderArgs).
 struct Counters {
@@ -18,8 +18,8 @@ struct Counters {
 	uint32_t next_item;      // next (tile, block run) to hand to a wave; only group 0's is used
 	uint32_t live;           // waves that still have or may get work
 	uint32_t pad;
-	unsigned long long shadow_rays;
-	unsigned long long ray_shard[kRayShards];      // closest-hit queries; the total is their sum
+	unsigned long long rays, shadow_rays;
+	uint32_t n_ray[2 * 2 * kShards];     // closest-hit queue lengths, [step parity][kind][shard]
 	unsigned long long inner, tri, sph;     // RTA_RENDER_COUNT_WORK only
 };
 
@@ -50,6 +50,8 @@ struct RenderArgs {
 	float4 *acc;                   // block sum rgb
 	uint4 *meta;                   // pixel, current block, end of the block run, index in the padded pixel list
 	uint32_t n_slots;
+	uint32_t *q_ray;               // closest-hit queues, [step parity][kind][shard][shard_cap] slot numbers
+	uint32_t shard_cap;            // entries per sub-queue, a multiple of the workgroup size
 	// occlusion queue, 3 per entry: (origin, limit) (direction, slot) (radiance, -)
 	float4 *shadow;
 	Counters *cnt;                 // this group's
@@ -69,9 +71,9 @@ struct RenderArgs {
 };
 
 void launch_init_slots(hipStream_t s, const RenderArgs &a, uint32_t n_slots);
-void launch_generate(hipStream_t s, const RenderArgs &a);
-void launch_intersect(hipStream_t s, const RenderArgs &a, int depth, bool count);
-void launch_shade(hipStream_t s, const RenderArgs &a);
+void launch_generate(hipStream_t s, const RenderArgs &a, int par);
+void launch_intersect(hipStream_t s, const RenderArgs &a, int par, int depth, bool count);
+void launch_shade(hipStream_t s, const RenderArgs &a, int par);
 void launch_shadow(hipStream_t s, const RenderArgs &a, uint32_t bound, int depth, bool count);
 void launch_sum_blocks(hipStream_t s, const float4 *partial, const int32_t *pixels, uint32_t n_pad, uint32_t n_blocks,
                        float *frame);

@@ -576,10 +576,10 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	HIP_TRY(ctx, ctx->col.reserve(S * 16));
 	HIP_TRY(ctx, ctx->acc.reserve(S * 16));
 	HIP_TRY(ctx, ctx->meta.reserve(S * 16));
-	// per group: 2 parities x 2 kinds x kShards sub-queues, each able to take
+	// per group: 2 parities x kRayKinds kinds x kShards sub-queues, each able to take
 	// everything its share of the group's workgroups can append in one launch
 	const uint32_t shard_cap = (uint32_t)((group_blocks + kShards - 1) / kShards) * 256;
-	const size_t group_queue = (size_t)4 * kShards * shard_cap;
+	const size_t group_queue = (size_t)2 * kRayKinds * kShards * shard_cap;
 	HIP_TRY(ctx, ctx->q_ray.reserve(group_queue * groups * 4));
 	if (ctx->n_lights > 0)
 		HIP_TRY(ctx, ctx->shadow.reserve(S * 48));

@@ -48,8 +48,9 @@ namespace {
 constexpr uint32_t kWaiting = 0xfffffffdu;     // through with its blocks; waits for the wave's next tile
 constexpr uint32_t kRetired = 0xfffffffeu;     // no work left for this wave
 constexpr uint32_t kEnded = 0xffffffffu;       // path finished; generate takes over
-// kinds of closest-hit rays, queued apart
-constexpr int kCameraRays = 0, kBounceRays = 1;
+// kinds of closest-hit rays, queued apart; kOddRays are the (rare) rays whose
+// box tests need the division-based form (see ray_is_tame), of either origin
+constexpr int kCameraRays = 0, kBounceRays = 1, kOddRays = 2;
 
 RTA_DEV float4 f4(V3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
 RTA_DEV float4 f4u(V3 v, uint32_t w) { return make_float4(v.x, v.y, v.z, __uint_as_float(w)); }
@@ -81,19 +82,29 @@ RTA_DEV void count_flush(Counters *cnt, const WorkCount &wc)
 
 // The closest-hit ray queues: [step parity][kind][shard][capacity] slot numbers,
 // lengths in Counters::n_ray in the same order.
-RTA_DEV uint32_t ray_queue_index(int par, int kind, uint32_t shard) { return ((uint32_t)par * 2 + (uint32_t)kind) * kShards + shard; }
+RTA_DEV uint32_t ray_queue_index(int par, int kind, uint32_t shard) { return ((uint32_t)par * kRayKinds + (uint32_t)kind) * kShards + shard; }
 
-RTA_DEV void ray_queue_push(const RenderArgs &a, int par, int kind, bool pred, uint32_t slot)
+// Queues `slot` (if pred) under `kind`, or under kOddRays when the ray needs the
+// division-based box test.  Must be reached by every lane of the wave.
+RTA_DEV void ray_queue_push(const RenderArgs &a, int par, int kind, bool pred, uint32_t slot, const Ray &ray)
 {
-	const uint32_t q = ray_queue_index(par, kind, blockIdx.x % kShards);
-	const uint32_t at = queue_push(pred, &a.cnt->n_ray[q]);
-	if (pred)
+	const bool tame = a.tree.tame != 0 && ray_is_tame(ray);
+	const uint32_t shard = blockIdx.x % kShards;
+	const uint32_t q = ray_queue_index(par, kind, shard);
+	const uint32_t at = queue_push(pred && tame, &a.cnt->n_ray[q]);
+	if (pred && tame)
 		a.q_ray[(size_t)q * a.shard_cap + at] = slot;
+	if (__ballot(pred && !tame)) {
+		const uint32_t qo = ray_queue_index(par, kOddRays, shard);
+		const uint32_t ato = queue_push(pred && !tame, &a.cnt->n_ray[qo]);
+		if (pred && !tame)
+			a.q_ray[(size_t)qo * a.shard_cap + ato] = slot;
+	}
 }
 
 // ------------------------------------------------------------------ generate
 
-RTA_DEV void camera_ray(const RenderArgs &a, uint32_t slot, uint32_t pixel, uint32_t rng, uint32_t done);
+RTA_DEV Ray camera_ray(const RenderArgs &a, uint32_t slot, uint32_t pixel, uint32_t rng, uint32_t done);
 
 // `par`: parity of the step whose intersect launch will trace the new rays.
 __global__ __launch_bounds__(kBlock) void k_generate(const RenderArgs a, const int par)
@@ -165,6 +176,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(const RenderArgs a, const i
 		}
 	}
 
+	Ray ray = {mk(0, 0, 0), mk(1, 1, 1)};
 	if (!need_ray) {
 		if (state != __float_as_uint(R1.w)) {
 			R1.w = __uint_as_float(state);
@@ -173,13 +185,13 @@ __global__ __launch_bounds__(kBlock) void k_generate(const RenderArgs a, const i
 	} else {
 		a.meta[slot] = M;
 		a.acc[slot] = A;
-		camera_ray(a, slot, M.x, rng, done);
+		ray = camera_ray(a, slot, M.x, rng, done);
 	}
-	ray_queue_push(a, par, kCameraRays, need_ray, slot);
+	ray_queue_push(a, par, kCameraRays, need_ray, slot, ray);
 }
 
 // One camera sample of pixel `pixel` (src/main.cpp:663-687) written into `slot`.
-RTA_DEV void camera_ray(const RenderArgs &a, uint32_t slot, uint32_t pixel, uint32_t rng, uint32_t done)
+RTA_DEV Ray camera_ray(const RenderArgs &a, uint32_t slot, uint32_t pixel, uint32_t rng, uint32_t done)
 {
 	const uint32_t pu = pixel % a.width, pv = pixel / a.width;
 	const V3 cam_o = mk(a.cam.origin[0], a.cam.origin[1], a.cam.origin[2]);
@@ -215,13 +227,30 @@ RTA_DEV void camera_ray(const RenderArgs &a, uint32_t slot, uint32_t pixel, uint
 	a.ray1[slot] = make_float4(dir.y, dir.z, 1.f, __uint_as_float(0u));     // bsdf_pdf = 1, bounce 0
 	a.thr[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(rng));
 	a.col[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(done));
+	return Ray{origin, dir};
 }
 
 // ------------------------------------------------------------------ intersect
 
-// Grid: 2 kinds x kShards sub-queues x (shard_cap / kBlock) workgroups, shards
-// innermost so that the first workgroups of all shards start together; a
-// workgroup whose part of its sub-queue is empty leaves at once.
+// Housekeeping done by the first workgroup of the first traversal launch of a
+// step: count the step's rays, empty the queues the previous step consumed,
+// empty the occlusion queue.
+RTA_DEV void step_housekeeping(const RenderArgs &a, int par)
+{
+	if (threadIdx.x < kRayKinds * kShards) {
+		const uint32_t n = a.cnt->n_ray[ray_queue_index(par, 0, 0) + threadIdx.x];
+		if (n)
+			atomicAdd(&a.cnt->rays, (unsigned long long)n);
+		a.cnt->n_ray[ray_queue_index(par ^ 1, 0, 0) + threadIdx.x] = 0;
+	}
+	if (threadIdx.x == 0)
+		a.cnt->n_shadow = 0;
+}
+
+// Camera and bounce rays.  Grid: 2 kinds x kShards sub-queues x
+// (shard_cap / kBlock) workgroups, shards innermost so that the first
+// workgroups of all shards start together; a workgroup whose part of its
+// sub-queue is empty leaves at once.
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_intersect(const RenderArgs a, const int par, const int depth)
 {
@@ -231,18 +260,8 @@ __global__ __launch_bounds__(kBlock) void k_intersect(const RenderArgs a, const 
 	const uint32_t shard = rem % kShards, part = rem / kShards;
 	const uint32_t q = ray_queue_index(par, (int)kind, shard);
 	const uint32_t total = a.cnt->n_ray[q];
-	if (blockIdx.x == 0) {
-		// housekeeping by the first workgroup: count this launch's rays, empty the
-		// queues the previous launch consumed, empty the occlusion queue
-		if (threadIdx.x < 2 * kShards) {
-			const uint32_t n = a.cnt->n_ray[ray_queue_index(par, 0, 0) + threadIdx.x];
-			if (n)
-				atomicAdd(&a.cnt->rays, (unsigned long long)n);
-			a.cnt->n_ray[ray_queue_index(par ^ 1, 0, 0) + threadIdx.x] = 0;
-		}
-		if (threadIdx.x == 0)
-			a.cnt->n_shadow = 0;
-	}
+	if (blockIdx.x == 0)
+		step_housekeeping(a, par);
 	const uint32_t i = part * kBlock + threadIdx.x;
 	WorkCount wc = {0, 0, 0};
 	if (i < total) {
@@ -250,7 +269,29 @@ __global__ __launch_bounds__(kBlock) void k_intersect(const RenderArgs a, const 
 		const float4 r0 = a.ray0[slot], r1 = a.ray1[slot];
 		Ray ray = {mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y)};
 		HitRec h;
-		traverse_dyn<false, COUNT>(a.tree, ray, FLT_MAX, lds_stack + threadIdx.x, depth, h, wc);
+		traverse_dyn<false, COUNT, true>(a.tree, ray, FLT_MAX, lds_stack + threadIdx.x, depth, h, wc);
+		a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
+	}
+	if (COUNT)
+		count_flush(a.cnt, wc);
+}
+
+// The rays that need the division-based box test.  Any grid that is a multiple
+// of kShards works: the workgroups of a shard stride over its sub-queue.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_intersect_odd(const RenderArgs a, const int par, const int depth)
+{
+	extern __shared__ uint32_t lds_stack[];
+	const uint32_t shard = blockIdx.x % kShards, part = blockIdx.x / kShards, parts = gridDim.x / kShards;
+	const uint32_t q = ray_queue_index(par, kOddRays, shard);
+	const uint32_t total = a.cnt->n_ray[q];
+	WorkCount wc = {0, 0, 0};
+	for (uint32_t i = part * kBlock + threadIdx.x; i < total; i += parts * kBlock) {
+		const uint32_t slot = a.q_ray[(size_t)q * a.shard_cap + i];
+		const float4 r0 = a.ray0[slot], r1 = a.ray1[slot];
+		Ray ray = {mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y)};
+		HitRec h;
+		traverse_dyn<false, COUNT, false>(a.tree, ray, FLT_MAX, lds_stack + threadIdx.x, depth, h, wc);
 		a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
 	}
 	if (COUNT)
@@ -264,6 +305,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(const RenderArgs a, const int 
 {
 	const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
 	bool want_shadow = false, alive = false;
+	Ray bounce_ray = {mk(0, 0, 0), mk(1, 1, 1)};
 	V3 sh_o = mk(0, 0, 0), sh_d = mk(0, 0, 0), sh_c = mk(0, 0, 0);
 	float sh_dist = 0;
 	float4 r1 = make_float4(0.f, 0.f, 0.f, __uint_as_float(kRetired));
@@ -380,6 +422,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(const RenderArgs a, const int 
 				const V3 nd = to_world(fr, s.l);
 				a.ray0[slot] = make_float4(point.x, point.y, point.z, nd.x);
 				a.ray1[slot] = make_float4(nd.y, nd.z, s.pdf, __uint_as_float(bounce + 1));
+				bounce_ray = Ray{point, nd};
 				alive = true;
 			}
 		}
@@ -389,7 +432,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(const RenderArgs a, const int 
 		a.col[slot] = make_float4(color.x, color.y, color.z, C.w);
 	}
 
-	ray_queue_push(a, par, kBounceRays, alive, slot);
+	ray_queue_push(a, par, kBounceRays, alive, slot, bounce_ray);
 	if (a.n_lights > 0) {
 		const uint32_t at_sh = queue_push(want_shadow, &a.cnt->n_shadow);
 		if (want_shadow) {
@@ -588,6 +631,13 @@ void launch_intersect(hipStream_t s, const RenderArgs &a, int par, int depth, bo
 		hipLaunchKernelGGL(k_intersect<true>, dim3(blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);
 	else
 		hipLaunchKernelGGL(k_intersect<false>, dim3(blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);
+	// on a tame tree odd rays are rare: one workgroup per sub-queue is plenty
+	const unsigned odd_blocks = a.tree.tame ? kShards : kShards * (a.shard_cap / kBlock);
+	if (count)
+		hipLaunchKernelGGL(k_intersect_odd<true>, dim3(odd_blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);
+	else
+		hipLaunchKernelGGL(k_intersect_odd<false>, dim3(odd_blocks), dim3(kBlock), stack_bytes(depth), s, a, par,
+		                   depth);
 }
 
 void launch_shade(hipStream_t s, const RenderArgs &a, int par)

@@ -11,6 +11,7 @@
 namespace rta {
 
 constexpr uint32_t kShards = 64;      // sub-queues per ray queue
+constexpr uint32_t kRayKinds = 3;     // camera rays, bounce rays, rays needing the division-based box test
 
 // Device-resident progress and statistics of one slot group (see RenderArgs).
 struct Counters {
@@ -19,7 +20,7 @@ struct Counters {
 	uint32_t live;           // waves that still have or may get work
 	uint32_t pad;
 	unsigned long long rays, shadow_rays;
-	uint32_t n_ray[2 * 2 * kShards];     // closest-hit queue lengths, [step parity][kind][shard]
+	uint32_t n_ray[2 * kRayKinds * kShards];     // closest-hit queue lengths, [step parity][kind][shard]
 	unsigned long long inner, tri, sph;     // RTA_RENDER_COUNT_WORK only
 };
 

@@ -112,14 +112,17 @@ RTA_DEV float quotient(float n, float d, float r)
 	return __builtin_fmaf(e, r, q);
 }
 
-RTA_DEV void slab_tame(float lo, float hi, float o, float d, float r, bool negative, float &tmin, float &tmax)
+// Entry and exit distance of one axis for a tame ray.  With finite quotients
+// the sign-bit selection of the reference equals taking the smaller quotient as
+// entry and the larger as exit (division by a positive d keeps the order of the
+// planes, by a negative d reverses it, and rounding is monotonic), so the planes
+// need no per-lane select.
+RTA_DEV void slab_tame(float lo, float hi, float o, float d, float r, float &t_in, float &t_out)
 {
-	float near_plane = negative ? hi : lo;
-	float far_plane = negative ? lo : hi;
-	float t1 = quotient(near_plane - o, d, r);
-	float t2 = quotient(far_plane - o, d, r);
-	tmin = greater(t1, tmin);
-	tmax = lesser(t2, tmax);
+	const float a = quotient(lo - o, d, r);
+	const float b = quotient(hi - o, d, r);
+	t_in = __builtin_fminf(a, b);
+	t_out = __builtin_fmaxf(a, b);
 }
 
 struct RaySigns {
@@ -158,12 +161,16 @@ RTA_DEV float test_box(V3 lo, V3 hi, const Ray &r, RaySigns s, float max_t)
 	return (tmax >= tmin && tmin < max_t && tmax > 0) ? tmin : FLT_MAX;
 }
 
-RTA_DEV float test_box_tame(V3 lo, V3 hi, const Ray &r, V3 rcp, RaySigns s, float max_t)
+RTA_DEV float test_box_tame(V3 lo, V3 hi, const Ray &r, V3 rcp, float max_t)
 {
-	float tmin = 0.f, tmax = FLT_MAX;
-	slab_tame(lo.x, hi.x, r.o.x, r.d.x, rcp.x, s.x, tmin, tmax);
-	slab_tame(lo.y, hi.y, r.o.y, r.d.y, rcp.y, s.y, tmin, tmax);
-	slab_tame(lo.z, hi.z, r.o.z, r.d.z, rcp.z, s.z, tmin, tmax);
+	float ix, ox, iy, oy, iz, oz;
+	slab_tame(lo.x, hi.x, r.o.x, r.d.x, rcp.x, ix, ox);
+	slab_tame(lo.y, hi.y, r.o.y, r.d.y, rcp.y, iy, oy);
+	slab_tame(lo.z, hi.z, r.o.z, r.d.z, rcp.z, iz, oz);
+	// the reference folds max(t, tmin) from 0 and min(t, tmax) from FLT_MAX
+	// (src/main.cpp:305-327); without NaNs the fold order does not matter
+	const float tmin = __builtin_fmaxf(__builtin_fmaxf(ix, iy), __builtin_fmaxf(iz, 0.f));
+	const float tmax = __builtin_fminf(__builtin_fminf(ox, oy), __builtin_fminf(oz, FLT_MAX));
 	return (tmax >= tmin && tmin < max_t && tmax > 0) ? tmin : FLT_MAX;
 }
 
@@ -179,7 +186,10 @@ RTA_DEV float test_box_tame(V3 lo, V3 hi, const Ray &r, V3 rcp, RaySigns s, floa
 // so consecutive lanes hit consecutive banks; upload guarantees the tree never
 // needs more than `depth` entries.  For ANY, `limit` is the distance bound and
 // the answer is prim >= 0.
-template <bool ANY, bool COUNT>
+//
+// TAME_ONLY promises that every ray given to start() passes ray_is_tame() on a
+// tame tree; the kernel then carries no code for the division-based box test.
+template <bool ANY, bool COUNT, bool TAME_ONLY = false>
 struct Traversal {
 	Ray ray;
 	V3 rcp;              // correctly rounded 1/direction (only used when tame)
@@ -196,7 +206,7 @@ struct Traversal {
 	{
 		ray = r;
 		sg = signs_of(r);
-		tame = tree.tame != 0 && ray_is_tame(r);
+		tame = TAME_ONLY || (tree.tame != 0 && ray_is_tame(r));
 		rcp = mk(1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z);
 		best = ANY ? limit : FLT_MAX;
 		prim = -1;
@@ -214,9 +224,9 @@ struct Traversal {
 			const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
 			const uint32_t ref1 = __float_as_uint(q3.x), ref2 = __float_as_uint(q3.y);
 			float d1, d2;
-			if (tame) {
-				d1 = test_box_tame(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), ray, rcp, sg, best);
-				d2 = test_box_tame(mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w), ray, rcp, sg, best);
+			if (TAME_ONLY || tame) {
+				d1 = test_box_tame(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), ray, rcp, best);
+				d2 = test_box_tame(mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w), ray, rcp, best);
 			} else {
 				d1 = test_box(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), ray, sg, best);
 				d2 = test_box(mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w), ray, sg, best);
@@ -298,11 +308,11 @@ struct Traversal {
 // wave64 spends its time converged: every lane first descends until it holds a
 // leaf (or runs out of work), then the lanes holding leaves test primitives
 // together.
-template <bool ANY, bool COUNT>
+template <bool ANY, bool COUNT, bool TAME_ONLY = false>
 RTA_DEV void traverse_dyn(const DeviceTree &tree, const Ray &ray, float limit, uint32_t *stack, const int depth,
                           HitRec &hit, WorkCount &work)
 {
-	Traversal<ANY, COUNT> tr;
+	Traversal<ANY, COUNT, TAME_ONLY> tr;
 	tr.start(tree, ray, limit);
 	for (;;) {
 		tr.descend(tree, stack, depth, work);

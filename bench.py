@@ -124,16 +124,10 @@ def main():
     s = scene.settings
 
     # outputs live in HBM: the shard's radiance sums land in a frame-sized buffer
+    from raytracer_amd.dist import ShardGather
     frame = torch.zeros((height, width, 3), dtype=torch.float32, device=dev)
     bgr = torch.zeros((height, width, 3), dtype=torch.uint8, device=dev)
-    mine = torch.from_numpy(rta.shard_pixels(width, height, rank, world).astype(np.int64)).to(dev)
-    counts = [len(rta.shard_pixels(width, height, r, world)) for r in range(world)]
-    pad = max(counts)
-    if world > 1:
-        everyone = torch.cat([torch.from_numpy(rta.shard_pixels(width, height, r, world).astype(np.int64))
-                              for r in range(world)]).to(dev)
-        send = torch.zeros((pad, 3), dtype=torch.float32, device=dev)
-        recv = torch.zeros((world, pad, 3), dtype=torch.float32, device=dev)
+    gatherer = ShardGather(width, height, rank, world, dev)
 
     p = rta.RenderParams(width=width, height=height, samples=spp, exposure=s.exposure, seed=69420,
                          samples_per_stream=args.samples_per_stream, shard_index=rank, shard_count=world,
@@ -144,11 +138,8 @@ def main():
     def step():
         st = ctx.render_device(cam, p, frame.data_ptr(), None)
         if world > 1:
-            # radiance gather over xGMI: equal-sized (padded) shards, then scatter to pixels
-            send[: counts[rank]] = frame.view(-1, 3)[mine]
-            dist.all_gather_into_tensor(recv.view(-1, 3), send)
-            parts = [recv[r, : counts[r]] for r in range(world)]
-            frame.view(-1, 3)[everyone] = torch.cat(parts)
+            # radiance gather over xGMI: one all-gather of equal-sized (padded) shards
+            gatherer.gather(frame, dist)
             torch.cuda.current_stream().synchronize()     # the resolve runs on the library's own stream
         ctx.resolve_device(frame.data_ptr(), width, height, spp, s.exposure, bgr.data_ptr())
         return st

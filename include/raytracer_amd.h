@@ -105,6 +105,9 @@ typedef struct {
 } rta_scene_desc;
 
 int rta_scene_describe(const rta_scene *scene, rta_scene_desc *out);
+/* The checks rta_upload_scene applies (index ranges, tree shape, depth <= 64,
+ * no primitive in two leaves), without a GPU.  err receives what is wrong. */
+int rta_validate_scene(const rta_scene_desc *desc, char *err, size_t errlen);
 /* BVH-order position -> position in the scene file (the build's permutation). */
 int rta_scene_permutation(const rta_scene *scene, const int32_t **perm, int32_t *n);
 

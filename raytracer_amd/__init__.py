@@ -80,6 +80,7 @@ _SIGNATURES = {
     "rta_scene_get_settings": (C.c_int, [C.c_void_p, C.POINTER(SceneSettings)]),
     "rta_scene_set_settings": (C.c_int, [C.c_void_p, C.POINTER(SceneSettings)]),
     "rta_scene_describe": (C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),
+    "rta_validate_scene": (C.c_int, [C.POINTER(SceneDesc), C.c_char_p, C.c_size_t]),
     "rta_scene_permutation": (C.c_int, [C.c_void_p, C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_int32)]),
     "rta_camera_from_settings": (C.c_int, [C.POINTER(SceneSettings), C.POINTER(Camera)]),
     "rta_write_bmp": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.c_void_p]),
@@ -266,6 +267,14 @@ def desc_from_arrays(a):
         setattr(d, key, ptr(key, np.float32, C.c_float))
     d._keep = keep
     return d
+
+
+def validate(desc):
+    """Raises RtaError with the library's explanation if the description is malformed."""
+    err = C.create_string_buffer(512)
+    rc = lib().rta_validate_scene(C.byref(desc), err, len(err))
+    if rc != OK:
+        raise RtaError(rc, err.value.decode(errors="replace"))
 
 
 def write_bmp(path, bgr):

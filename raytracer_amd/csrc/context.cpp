@@ -368,6 +368,20 @@ void shard_pixels(int32_t w, int32_t h, int32_t shard, int32_t n_shards, bool pa
 
 extern "C" {
 
+int rta_validate_scene(const rta_scene_desc *desc, char *err, size_t errlen)
+{
+	if (!desc)
+		return RTA_E_INVALID;
+	Flattened f;
+	std::string problem = flatten(*desc, f);
+	if (problem.empty())
+		return RTA_OK;
+	set_global_error("invalid scene: " + problem);
+	if (err && errlen)
+		snprintf(err, errlen, "%s", problem.c_str());
+	return RTA_E_INVALID;
+}
+
 int rta_upload_scene(rta_context *ctx, const rta_scene_desc *desc)
 {
 	if (!ctx)

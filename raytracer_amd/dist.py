@@ -1,0 +1,40 @@
+"""Assembling one frame from per-GPU shards with torch.distributed.
+
+Each rank renders the 8x8 tiles with tile_id % world == rank
+(rta_shard_pixels); the radiance sums of all ranks are brought together with
+ONE all-gather of equally sized (padded) shard buffers - over RCCL/xGMI when
+the tensors live on GPUs, over gloo in the CPU tests - and scattered back to
+pixel positions.  Nothing else is exchanged: pixels are independent.
+"""
+import numpy as np
+import torch
+
+from . import shard_pixels
+
+
+class ShardGather:
+    def __init__(self, width, height, rank, world, device):
+        self.rank, self.world = rank, world
+        lists = [shard_pixels(width, height, r, world).astype(np.int64) for r in range(world)]
+        self.counts = [len(x) for x in lists]
+        self.pad = max(self.counts) if self.counts else 0
+        self.mine = torch.from_numpy(lists[rank]).to(device)
+        self.everyone = torch.from_numpy(np.concatenate(lists)).to(device)
+        self.send = torch.zeros((self.pad, 3), dtype=torch.float32, device=device)
+        self.recv = torch.zeros((world, self.pad, 3), dtype=torch.float32, device=device)
+
+    def gather(self, frame, dist):
+        """frame: [height, width, 3] float32 holding this rank's pixels; on
+        return it holds every rank's pixels."""
+        if self.world == 1:
+            return frame
+        flat = frame.view(-1, 3)
+        self.send[: self.counts[self.rank]] = flat[self.mine]
+        dist.all_gather_into_tensor(self.recv.view(-1, 3), self.send)
+        parts = [self.recv[r, : self.counts[r]] for r in range(self.world)]
+        flat[self.everyone] = torch.cat(parts)
+        return frame
+
+    @property
+    def bytes_per_rank(self):
+        return self.pad * 12

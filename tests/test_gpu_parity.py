@@ -163,3 +163,85 @@ def test_render_bit_exact(gpu, name, w, h, spp, sps, slots):
     same = bits(acc) == bits(want_acc)
     assert same.all(), f"{(~same).any(axis=2).sum()} of {w * h} pixels differ in radiance bits"
     assert np.array_equal(bgr, want_bgr)
+
+
+@pytest.mark.parametrize("name,w,h,spp,sps", [("cornell_box.txt", 70, 44, 4, 2), ("dragon.txt", 64, 64, 4, 4)])
+def test_shards_assemble_to_the_single_gpu_frame(gpu, name, w, h, spp, sps):
+    """Tile sharding is exact: rendering the shards of a 1-, 2-, 3- and 8-way
+    split one after the other gives the bits of the unsharded render."""
+    osc, psc = load_pair(name)
+    psc.set_render(w, h, spp)
+    gpu.upload(psc)
+    whole_bgr, whole_acc, whole_st = gpu.render_scene(psc, seed=5, samples_per_stream=sps)
+    for n in (2, 3, 8):
+        acc = np.zeros_like(whole_acc)
+        bgr = np.zeros_like(whole_bgr)
+        rays = 0
+        for r in range(n):
+            b, a, st = gpu.render_scene(psc, seed=5, samples_per_stream=sps, shard_index=r, shard_count=n)
+            px = rta.shard_pixels(w, h, r, n)
+            untouched = np.ones(w * h, bool)
+            untouched[px] = False
+            assert not a.reshape(-1, 3)[untouched].any(), "a shard wrote pixels it does not own"
+            acc += a
+            bgr += b
+            rays += st["rays"]
+        assert np.array_equal(bits(acc), bits(whole_acc)), n
+        assert np.array_equal(bgr, whole_bgr), n
+        assert rays == whole_st["rays"]
+    # the resolve entry point reproduces the bytes from the gathered sums
+    assert np.array_equal(gpu.resolve(whole_acc, spp, psc.settings.exposure), whole_bgr)
+
+
+def test_scheduling_knobs_do_not_change_the_image(gpu):
+    osc, psc = load_pair("cornell_box.txt")
+    psc.set_render(40, 24, 6)
+    gpu.upload(psc)
+    base = gpu.render_scene(psc, seed=9, samples_per_stream=2)[1]
+    for kw in (dict(slots=64), dict(slots=100000, streams=1), dict(streams=8, run_blocks=3), dict(run_blocks=1, streams=2)):
+        other = gpu.render_scene(psc, seed=9, samples_per_stream=2, **kw)[1]
+        assert np.array_equal(bits(other), bits(base)), kw
+
+
+def test_edge_inputs(gpu):
+    osc, psc = load_pair("cornell_box.txt")
+    gpu.upload(psc)
+    assert len(gpu.trace_closest(np.zeros((0, 6), np.float32))) == 0
+    # NaN and zero directions must come back as misses, not hang or fault
+    weird = np.float32([[0, 0, 1, 0, 0, 0], [0, 0, 1, np.nan, 0, 1], [np.inf, 0, 1, 1, 0, 0], [0, 0, 1, 1e-30, 1, 0]])
+    want = osc.trace_closest(weird)[0]
+    assert np.array_equal(gpu.trace_closest(weird)["prim"], want)
+    with pytest.raises(rta.RtaError):
+        gpu.render(psc.camera(), 0, 10, 1)
+    with pytest.raises(rta.RtaError):
+        gpu.render(psc.camera(), 8, 8, 1, shard_index=2, shard_count=2)
+    fresh = rta.Context(0)
+    with pytest.raises(rta.RtaError) as e:
+        fresh.trace_closest(weird)
+    assert e.value.code == rta.E_NO_SCENE
+    fresh.close()
+
+
+def test_single_pixel_and_single_sample(gpu):
+    osc, psc = load_pair("dragon.txt")
+    for w, h, spp in ((1, 1, 1), (1, 9, 2), (9, 1, 1)):
+        osc.set_render(w, h, spp)
+        psc.set_render(w, h, spp)
+        gpu.upload(psc)
+        want = osc.render(orc.RNG_STREAM, orc.MATH_PM, seed=2, samples_per_stream=0)[1]
+        got = gpu.render_scene(psc, seed=2)[1]
+        assert np.array_equal(bits(got), bits(want)), (w, h, spp)
+
+
+def test_features_unused_by_the_shipped_scenes(gpu):
+    """Defocus lens sampling, exposure, a rough metal and a second sphere."""
+    text = orc.scene_variant("cornell_box.txt", 56, 40, 5).replace(
+        "look_at [0 0 1]", "look_at [0 0 1]\n\tdefocus_angle 2.5\n\texposure 1.7\n\tfov 70")
+    text += "\nmaterial { color [0.9 0.8 0.3] roughness 0.35 metallic 1 ior 1.8 }\nsphere { center [0.3 -0.4 0.25] radius 0.25 }\n"
+    osc = orc.Scene.parse(text).build_bvh()
+    psc = rta.Scene.parse(text).build_bvh()
+    gpu.upload(psc)
+    want_bgr, want_acc, _ = osc.render(orc.RNG_STREAM, orc.MATH_PM, seed=21, samples_per_stream=2)
+    bgr, acc, _ = gpu.render_scene(psc, seed=21, samples_per_stream=2)
+    assert np.array_equal(bits(acc), bits(want_acc))
+    assert np.array_equal(bgr, want_bgr)

@@ -245,3 +245,25 @@ def test_features_unused_by_the_shipped_scenes(gpu):
     bgr, acc, _ = gpu.render_scene(psc, seed=21, samples_per_stream=2)
     assert np.array_equal(bits(acc), bits(want_acc))
     assert np.array_equal(bgr, want_bgr)
+
+
+def test_triangle_soup_indices_bit_exact(gpu):
+    """The intersect-only workload at test size: 200 k random triangles, a
+    coherent pinhole grid and incoherent rays; every index and t must match."""
+    rng = np.random.default_rng(1)
+    n = 200_000
+    c = rng.uniform(-1, 1, (n, 1, 3)).astype(np.float32)
+    tri = (c + rng.uniform(-0.01, 0.01, (n, 3, 3)).astype(np.float32)).reshape(n, 9)
+    osc = orc.Scene.from_triangles(tri).build_bvh()
+    psc = rta.Scene.from_triangles(tri).build_bvh()
+    gpu.upload(psc)
+    osc.set_camera((-3, 0, 0), (0, 0, 0), fov=40.0).set_render(512, 512, 1)
+    coherent = raygen.camera_grid(osc.camera(), 512, 512)
+    incoherent = raygen.random_rays(300_000, (-1, -1, -1), (1, 1, 1), seed=3)
+    for label, rr in (("coherent", coherent), ("incoherent", incoherent)):
+        idx, t, u, v = osc.trace_closest(rr)
+        hits = gpu.trace_closest(rr)
+        assert np.array_equal(hits["prim"], idx), label
+        assert np.array_equal(bits(hits["t"]), bits(t)), label
+        assert np.array_equal(bits(hits["u"]), bits(u)) and np.array_equal(bits(hits["v"]), bits(v)), label
+        assert 0.05 < (idx >= 0).mean() < 0.999, label

@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""Intersect-only microbenchmark: a seed-fixed random triangle soup, coherent
+and incoherent ray batches resident in HBM, closest-hit through the C ABI.
+
+    python tools/bench_soup.py [--tris 10000000] [--rays 67108864] [--check 1048576]
+
+The tree is the reference builder's (restated in rta_scene_build_bvh; the
+reference binary itself stops at 16384 objects).  Correctness: a strided subset
+of each batch is traced by the CPU checker and must agree bit for bit in
+primitive index and t; a checksum over all indices is printed.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+
+import raytracer_amd as rta
+
+
+def make_soup(n, seed=1):
+    """Centres uniform in [-1,1]^3, vertices = centre + uniform [-0.01,0.01]^3."""
+    rng = np.random.default_rng(seed)
+    out = np.empty((n, 9), np.float32)
+    step = 1 << 20
+    for a in range(0, n, step):
+        m = min(step, n - a)
+        c = rng.uniform(-1, 1, (m, 1, 3)).astype(np.float32)
+        out[a:a + m] = (c + rng.uniform(-0.01, 0.01, (m, 3, 3)).astype(np.float32)).reshape(m, 9)
+    return out
+
+
+def coherent_rays(side, dev):
+    """A side x side pinhole grid from (-3, 0, 0) looking at the origin, 40 degrees wide."""
+    half = float(np.tan(np.radians(20.0)))
+    t = (torch.arange(side, device=dev, dtype=torch.float32) + 0.5) / side * 2 - 1
+    y = (t * half).view(1, side).expand(side, side)
+    z = (-t * half).view(side, 1).expand(side, side)
+    d = torch.stack([torch.ones_like(y), y, z], dim=-1).reshape(-1, 3)
+    d = d / d.norm(dim=1, keepdim=True)
+    o = torch.tensor([-3.0, 0.0, 0.0], device=dev).expand_as(d)
+    return torch.cat([o, d], dim=1).contiguous()
+
+
+def incoherent_rays(n, dev, seed=2):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    o = torch.rand((n, 3), device=dev, generator=g) * 2 - 1
+    d = torch.randn((n, 3), device=dev, generator=g)
+    d = d / d.norm(dim=1, keepdim=True)
+    return torch.cat([o, d], dim=1).contiguous()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tris", type=int, default=10_000_000)
+    ap.add_argument("--rays", type=int, default=64 * 1024 * 1024)
+    ap.add_argument("--check", type=int, default=1 << 20, help="rays per batch verified against the CPU checker")
+    ap.add_argument("--reps", type=int, default=3)
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+
+    t0 = time.perf_counter()
+    soup = make_soup(args.tris)
+    scene = rta.Scene.from_triangles(soup).build_bvh()
+    build_s = time.perf_counter() - t0
+    d = scene.desc()
+    ctx = rta.Context(0)
+    ctx.upload(scene)
+    print(f"soup: {d.n_prims} triangles, {d.n_nodes} nodes, parse+build {build_s:.1f} s", flush=True)
+
+    checker = None
+    if args.check:
+        import orc
+        t0 = time.perf_counter()
+        checker = orc.Scene.from_triangles(soup).build_bvh()
+        print(f"checker tree built in {time.perf_counter() - t0:.1f} s, depth {checker.depth()}", flush=True)
+
+    side = int(round(args.rays ** 0.5))
+    batches = {"coherent": coherent_rays(side, dev), "incoherent": incoherent_rays(args.rays, dev)}
+    report = {"triangles": int(d.n_prims), "nodes": int(d.n_nodes), "batches": {}}
+    for name, rays in batches.items():
+        n = rays.shape[0]
+        hits = torch.empty((n, 4), dtype=torch.float32, device=dev)
+        ctx.trace_closest_device(rays.data_ptr(), n, hits.data_ptr())
+        best = 1e9
+        for _ in range(args.reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ctx.trace_closest_device(rays.data_ptr(), n, hits.data_ptr())
+            best = min(best, time.perf_counter() - t0)
+        prim = hits[:, 0].view(torch.int32)
+        entry = {"rays": n, "ms": best * 1e3, "mrays_per_s": n / best / 1e6,
+                 "hit_fraction": float((prim >= 0).float().mean()),
+                 "index_checksum": int((prim.long() * (torch.arange(n, device=dev) % 1000003 + 1)).sum().item())}
+        if checker is not None:
+            stride = max(1, n // args.check)
+            sub = rays[::stride].cpu().numpy()
+            idx, t, _, _, cn = checker.trace_closest(sub, counters=True)
+            got = hits[::stride].cpu().numpy()
+            same = np.array_equal(got[:, 0].view(np.int32), idx) and np.array_equal(got[:, 1].view(np.uint32),
+                                                                                     t.view(np.uint32))
+            entry.update({"checked": int(len(sub)), "bit_exact": bool(same),
+                          "inner_visits_per_ray": float(cn[3]) / len(sub), "tri_tests_per_ray": float(cn[4]) / len(sub)})
+            entry["bytes_per_ray"] = 64 * entry["inner_visits_per_ray"] + 36 * entry["tri_tests_per_ray"] + 40
+            entry["algorithmic_gb_per_s"] = entry["bytes_per_ray"] * n / best / 1e9
+            entry["hbm_fraction_of_8tbs"] = entry["algorithmic_gb_per_s"] / 8000.0
+            if not same:
+                bad = np.nonzero(got[:, 0].view(np.int32) != idx)[0]
+                print(f"MISMATCH in {name}: {len(bad)} indices differ, first ray {sub[bad[0]] if len(bad) else None}")
+        report["batches"][name] = entry
+        print(name, json.dumps(entry), flush=True)
+        del hits
+    print(json.dumps(report))
+    ok = all(b.get("bit_exact", True) for b in report["batches"].values())
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()

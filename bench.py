@@ -201,8 +201,17 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "k_intersect", "avg_launch_ms": avg_ms, "launches": launches,
                          "rays_per_launch": rays_per_launch, "bytes_per_ray": w["bytes_per_ray"],
-                         "intersect_share_of_gpu_time": tot["intersect_ms"] / max(tot["gpu_ms"], 1e-9)},
+                         "concurrent_streams": args.streams or 4,
+                         "intersect_launch_time_over_gpu_time": tot["intersect_ms"] / max(tot["gpu_ms"], 1e-9)},
         }
+        # HBM bytes per intersect launch from the committed PMC profile of this workload
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                tj = json.load(f)
+            if tj.get("workload") == w["label"] and tj.get("kernel") == "k_intersect":
+                line["roofline"]["traffic"] = tj["hbm_bytes_per_ray"] * rays_per_launch
+                line["roofline"]["traffic_source"] = "profiles/traffic.json (%s)" % tj.get("tag")
         if args.count_work and tot["rays"]:
             line["roofline"]["measured_bytes_per_ray"] = (64.0 * tot["inner_visits"] + 36.0 * tot["tri_tests"] +
                                                           16.0 * tot["sph_tests"]) / (tot["rays"] +

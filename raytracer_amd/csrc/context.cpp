@@ -561,7 +561,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	const uint32_t spp = (uint32_t)p->samples;
 	const uint32_t sps = p->samples_per_stream <= 0 ? spp : std::min((uint32_t)p->samples_per_stream, spp);
 	const uint32_t n_blocks = (spp + sps - 1) / sps;
-	const uint32_t run_blocks = p->run_blocks > 0 ? std::min((uint32_t)p->run_blocks, n_blocks) : std::min(2u, n_blocks);
+	const uint32_t run_blocks = p->run_blocks > 0 ? std::min((uint32_t)p->run_blocks, n_blocks) : 1u;
 	const uint32_t n_runs = (n_blocks + run_blocks - 1) / run_blocks;
 	const uint64_t items64 = (uint64_t)n_tiles * n_runs;          // (tile, block run) pairs, one per wave at a time
 	const size_t frame_px = (size_t)p->width * p->height;

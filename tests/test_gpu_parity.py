@@ -267,3 +267,41 @@ def test_triangle_soup_indices_bit_exact(gpu):
         assert np.array_equal(bits(hits["t"]), bits(t)), label
         assert np.array_equal(bits(hits["u"]), bits(u)) and np.array_equal(bits(hits["v"]), bits(v)), label
         assert 0.05 < (idx >= 0).mean() < 0.999, label
+
+
+@pytest.mark.parametrize("name,spp", [("dragon.txt", 8), ("cornell_box.txt", 2)])
+def test_full_resolution_frames_bit_exact(gpu, name, spp):
+    """1920x1080 (the benchmark's frame size) at a sample count the CPU checker
+    finishes in seconds: every one of the 2 M pixels must carry the checker's
+    radiance bits and bytes."""
+    osc, psc = load_pair(name)
+    osc.set_render(1920, 1080, spp)
+    psc.set_render(1920, 1080, spp)
+    gpu.upload(psc)
+    want_bgr, want_acc, want_cn = osc.render(orc.RNG_STREAM, orc.MATH_PM, seed=69420, samples_per_stream=4)
+    bgr, acc, st = gpu.render_scene(psc, seed=69420, samples_per_stream=4)
+    assert st["rays"] == want_cn["rays"] and st["shadow_rays"] == want_cn["shadow_rays"]
+    assert np.array_equal(bits(acc), bits(want_acc))
+    assert np.array_equal(bgr, want_bgr)
+
+
+def test_benchmark_size_properties(gpu):
+    """dragon 1080p at 256 spp (a quarter of the benchmark's samples, same
+    kernels and queues at full occupancy): sky pixels resolve to the exact sky
+    bytes, the frame agrees with a low-sample frame of different blocks within
+    Monte-Carlo noise, and splitting the samples into blocks differently moves
+    only the noise."""
+    osc, psc = load_pair("dragon.txt")
+    psc.set_render(1920, 1080, 256)
+    gpu.upload(psc)
+    bgr, acc, st = gpu.render_scene(psc, seed=69420, samples_per_stream=32)
+    assert st["samples"] == 1920 * 1080 * 256
+    assert 1.15 < st["rays"] / st["samples"] < 1.26            # 1.206 in the reference's own traversal
+    # a pixel all of whose 256 samples left the scene sums to exactly 256 * sky (8 block sums of 32 samples)
+    pure_sky = (acc == np.float32([128, 128, 256])).all(axis=2)
+    assert 0.87 < pure_sky.mean() < 0.895                      # 89.0 % of the frame is sky at 1080p
+    assert (bgr[pure_sky] == np.uint8([187, 156, 156])).all()  # B,G,R bytes of the sky colour (.5,.5,1)
+    psc.set_render(1920, 1080, 16)
+    low = gpu.render_scene(psc, seed=7, samples_per_stream=16)[0].astype(np.float64)
+    rmse = float(np.sqrt(np.mean((low - bgr.astype(np.float64)) ** 2)))
+    assert rmse < 2.5, rmse                                    # noise of the 16-spp frame: ~1.5 expected

@@ -220,6 +220,12 @@ int64_t rta_shard_pixels(int32_t width, int32_t height, int32_t shard_index, int
  * 8 the traversal's reciprocal-based quotient of x by y. */
 int rta_debug_arith(rta_context *ctx, int op, const float *x, const float *y, float *out, int64_t n);
 
+/* Measurement hook: closest hit as rta_trace_closest (variant 0) or with one
+ * design decision changed - 1 traversal stack in private memory, 2 division-based
+ * box test for every ray, 3 the reference's 32-byte node array with a node-number
+ * stack.  Same results; variants 1..3 take device pointers only. */
+int rta_debug_trace_variant(rta_context *ctx, int variant, const float *rays, int64_t n, rta_hit *hits, int mem);
+
 void *rta_stream(rta_context *ctx);     /* the hipStream_t all work of the context is enqueued on */
 
 #ifdef __cplusplus

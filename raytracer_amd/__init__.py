@@ -3,6 +3,10 @@ backend.  The C ABI is declared in include/raytracer_amd.h; this module is a
 thin convenience layer for tests, the benchmark and scripts.  All compute runs
 in the HIP library: there is no Python or CPU fallback, and a missing library
 or GPU raises.
+
+A process that also uses torch on the GPU must `import torch` BEFORE the first
+call into this module: the torch wheel bundles its own HIP runtime, and the
+runtime that is loaded second finds no devices.
 """
 import ctypes as C
 import os
@@ -98,6 +102,7 @@ _SIGNATURES = {
                               C.c_int]),
     "rta_shard_pixels": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "rta_debug_arith": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "rta_debug_trace_variant": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]),
     "rta_stream": (C.c_void_p, [C.c_void_p]),
 }
 
@@ -337,6 +342,9 @@ class Context:
 
     def trace_closest_device(self, rays_ptr, n, hits_ptr):
         self._check(lib().rta_trace_closest(self._h, rays_ptr, n, hits_ptr, MEM_DEVICE))
+
+    def trace_variant_device(self, variant, rays_ptr, n, hits_ptr):
+        self._check(lib().rta_debug_trace_variant(self._h, variant, rays_ptr, n, hits_ptr, MEM_DEVICE))
 
     def trace_occluded(self, rays, tmax):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)

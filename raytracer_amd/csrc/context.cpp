@@ -68,7 +68,7 @@ struct rta_context {
 
 	// scene
 	bool have_scene = false;
-	DeviceBuffer pairs, prims, shade_prims, materials, lights;
+	DeviceBuffer pairs, prims, shade_prims, materials, lights, ref_nodes;
 	uint32_t root_ref = 0;
 	bool tame = false;           // box coordinates allow the reciprocal slab test (traverse.hpp)
 	int stack_depth = 1;
@@ -177,6 +177,7 @@ namespace {
 
 struct Flattened {
 	std::vector<float4> pairs, prims, shade, mats, lights;
+	std::vector<float4> ref_nodes;     // the reference's 32-byte node records, for the layout probe only
 	uint32_t root = 0;
 	int depth = 0;
 	bool tame = true;
@@ -285,9 +286,21 @@ std::string flatten(const rta_scene_desc &d, Flattened &out)
 		out.pairs[p * 4 + 0] = make_float4(a[0], a[1], a[2], a[3]);
 		out.pairs[p * 4 + 1] = make_float4(a[4], a[5], b[0], b[1]);
 		out.pairs[p * 4 + 2] = make_float4(b[2], b[3], b[4], b[5]);
-		out.pairs[p * 4 + 3] = make_float4(as_float(ref_of(l)), as_float(ref_of(r)), 0, 0);
+		auto counted = [&](int32_t node) -> uint32_t {
+			if (d.node_count[node] <= 0)
+				return ref_of(node);
+			return kLeaf | ((uint32_t)(std::min(d.node_count[node], 128) - 1) << 24) | ((uint32_t)d.node_index[node] & 0xffffffu);
+		};
+		out.pairs[p * 4 + 3] = make_float4(as_float(ref_of(l)), as_float(ref_of(r)), as_float(counted(l)), as_float(counted(r)));
 	}
 
+	out.ref_nodes.resize((size_t)d.n_nodes * 2);
+	for (int32_t k = 0; k < d.n_nodes; k++) {
+		const float *b = d.node_bounds + (size_t)k * 6;
+		out.ref_nodes[(size_t)k * 2] = make_float4(b[0], b[1], b[2], b[3]);
+		out.ref_nodes[(size_t)k * 2 + 1] =
+		    make_float4(b[4], b[5], as_float((uint32_t)d.node_index[k]), as_float((uint32_t)d.node_count[k]));
+	}
 	out.prims.resize((size_t)d.n_prims * 3);
 	out.shade.resize((size_t)d.n_prims * 3);
 	for (int32_t k = 0; k < d.n_prims; k++) {
@@ -397,7 +410,7 @@ int rta_upload_scene(rta_context *ctx, const rta_scene_desc *desc)
 	int rc;
 	if ((rc = upload_vec(ctx, ctx->pairs, f.pairs)) || (rc = upload_vec(ctx, ctx->prims, f.prims)) ||
 	    (rc = upload_vec(ctx, ctx->shade_prims, f.shade)) || (rc = upload_vec(ctx, ctx->materials, f.mats)) ||
-	    (rc = upload_vec(ctx, ctx->lights, f.lights)))
+	    (rc = upload_vec(ctx, ctx->lights, f.lights)) || (rc = upload_vec(ctx, ctx->ref_nodes, f.ref_nodes)))
 		return rc;
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // the staging vectors die with this call
 	ctx->root_ref = f.root;
@@ -448,6 +461,24 @@ int rta_trace_closest(rta_context *ctx, const float *rays, int64_t n, rta_hit *h
 	HIP_TRY(ctx, hipGetLastError());
 	if (mem == RTA_MEM_HOST)
 		HIP_TRY(ctx, hipMemcpyAsync(hits, d_hits, (size_t)n * sizeof(rta_hit), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return RTA_OK;
+}
+
+int rta_debug_trace_variant(rta_context *ctx, int variant, const float *rays, int64_t n, rta_hit *hits, int mem)
+{
+	if (!ctx)
+		return RTA_E_INVALID;
+	if (variant == 0)
+		return rta_trace_closest(ctx, rays, n, hits, mem);
+	if (!ctx->have_scene)
+		return ctx->fail(RTA_E_NO_SCENE, "no scene uploaded");
+	if (variant < 1 || variant > 5 || n <= 0 || !rays || !hits || mem != RTA_MEM_DEVICE)
+		return ctx->fail(RTA_E_INVALID, "variants 1..3 take device-resident ray batches");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	launch_variant(ctx->stream, variant, tree_of(ctx), ctx->ref_nodes.as<const float4>(), rays, (uint64_t)n, hits,
+	               ctx->stack_depth);
+	HIP_TRY(ctx, hipGetLastError());
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	return RTA_OK;
 }

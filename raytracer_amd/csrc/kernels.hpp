@@ -85,5 +85,9 @@ void launch_batch_closest(hipStream_t s, const TreeRef &tree, const float *rays,
 void launch_batch_occluded(hipStream_t s, const TreeRef &tree, const float *rays, const float *tmax, uint64_t n,
                            uint8_t *out, int depth);
 void launch_arith(hipStream_t s, int op, const float *x, const float *y, float *out, uint64_t n);
+// variants.hip: closest hit with one design decision changed (1 private stack,
+// 2 division-based box test, 3 reference node layout); measurement only
+void launch_variant(hipStream_t s, int variant, const TreeRef &tree, const float4 *reference_nodes, const float *rays,
+                    uint64_t n, rta_hit *hits, int depth);
 
 }  // namespace rta

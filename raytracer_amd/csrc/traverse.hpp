@@ -175,12 +175,9 @@ RTA_DEV float test_box_tame(V3 lo, V3 hi, const Ray &r, V3 rcp, float max_t)
 }
 
 // Traversal of src/main.cpp:332-422 (closest, ANY = false) and :424-478 (any
-// hit, ANY = true), kept as an explicit per-lane state machine so that a kernel
-// can interleave the two phases of many rays and swap finished rays for new
-// ones between phases:
-//
-//   descend()  walks inner nodes until the lane holds a leaf or is finished
-//   leaf()     tests the leaf's primitives, then pops the next pending node
+// hit, ANY = true), kept as an explicit per-lane state machine: step() does one
+// unit of work, either one inner-node visit (both child boxes) or one primitive
+// test, and leaves in `node` what the lane does next.
 //
 // `stack` points at the lane's column of an LDS array laid out [depth][kBlock],
 // so consecutive lanes hit consecutive banks; upload guarantees the tree never
@@ -216,9 +213,41 @@ struct Traversal {
 		more = true;
 	}
 
-	RTA_DEV void descend(const DeviceTree &tree, uint32_t *stack, const int depth, WorkCount &work)
+	// One unit of work: either one inner-node visit or one primitive test.
+	// Precondition: more.
+	RTA_DEV void step(const DeviceTree &tree, uint32_t *stack, const int depth, WorkCount &work)
 	{
-		while (more && !(node & kLeafBit)) {
+		if (node & kLeafBit) {
+			const uint32_t i = node & ~kLeafBit;
+			const float4 p0 = tree.prims[3 * (size_t)i];
+			const float4 p1 = tree.prims[3 * (size_t)i + 1];
+			const uint32_t flags = __float_as_uint(p0.w);
+			float t, tu = 0, tv = 0;
+			if (flags & kPrimSphere) {
+				if (COUNT) work.sph++;
+				t = test_sphere(mk(p0.x, p0.y, p0.z), p1.x, ray);
+			} else {
+				if (COUNT) work.tri++;
+				const float4 p2 = tree.prims[3 * (size_t)i + 2];
+				t = test_triangle(mk(p0.x, p0.y, p0.z), mk(p1.x, p1.y, p1.z), mk(p2.x, p2.y, p2.z), ray, tu, tv);
+			}
+			if (t < best) {           // strict: the first-visited primitive keeps a tie
+				prim = (int32_t)i;
+				if (ANY) {
+					more = false;
+					return;
+				}
+				best = t;
+				u = tu;
+				v = tv;
+			}
+			if (!(flags & kPrimLast))
+				node = node + 1;      // next primitive of the same leaf
+			else if (sp > 0)
+				node = stack[(--sp) * kBlock];
+			else
+				more = false;
+		} else {
 			if (COUNT) work.inner++;
 			const float4 *rec = tree.pairs + 4 * (size_t)node;
 			const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
@@ -264,63 +293,25 @@ struct Traversal {
 		}
 	}
 
-	// Precondition: more && (node & kLeafBit)
-	RTA_DEV void leaf(const DeviceTree &tree, uint32_t *stack, WorkCount &work)
-	{
-		uint32_t i = node & ~kLeafBit;
-		for (;;) {
-			const float4 p0 = tree.prims[3 * (size_t)i];
-			const float4 p1 = tree.prims[3 * (size_t)i + 1];
-			const uint32_t flags = __float_as_uint(p0.w);
-			float t, tu = 0, tv = 0;
-			if (flags & kPrimSphere) {
-				if (COUNT) work.sph++;
-				t = test_sphere(mk(p0.x, p0.y, p0.z), p1.x, ray);
-			} else {
-				if (COUNT) work.tri++;
-				const float4 p2 = tree.prims[3 * (size_t)i + 2];
-				t = test_triangle(mk(p0.x, p0.y, p0.z), mk(p1.x, p1.y, p1.z), mk(p2.x, p2.y, p2.z), ray, tu, tv);
-			}
-			if (t < best) {           // strict: the first-visited primitive keeps a tie
-				prim = (int32_t)i;
-				if (ANY) {
-					more = false;
-					return;
-				}
-				best = t;
-				u = tu;
-				v = tv;
-			}
-			if (flags & kPrimLast)
-				break;
-			i++;
-		}
-		if (sp > 0)
-			node = stack[(--sp) * kBlock];
-		else
-			more = false;
-	}
-
 	RTA_DEV HitRec result() const { return HitRec{prim, ANY ? 0.f : best, u, v}; }
 };
 
-// One ray per lane from start to finish.  The two phases alternate so that a
-// wave64 spends its time converged: every lane first descends until it holds a
-// leaf (or runs out of work), then the lanes holding leaves test primitives
-// together.
+// One ray per lane from start to finish.  Each trip of the loop gives every
+// unfinished lane exactly one unit of work (an inner-node visit or a primitive
+// test).  The loop condition is a wave-wide ballot: a convergent operation the
+// compiler may not duplicate into the two branches, which keeps this ONE loop
+// instead of a nest of "descend" and "leaf" loops in which lanes wait for the
+// slowest lane of each inner loop (measured: 23 % instead of 16 % of the lanes
+// active per vector instruction on bounce rays).
 template <bool ANY, bool COUNT, bool TAME_ONLY = false>
 RTA_DEV void traverse_dyn(const DeviceTree &tree, const Ray &ray, float limit, uint32_t *stack, const int depth,
                           HitRec &hit, WorkCount &work)
 {
 	Traversal<ANY, COUNT, TAME_ONLY> tr;
 	tr.start(tree, ray, limit);
-	for (;;) {
-		tr.descend(tree, stack, depth, work);
-		if (!tr.more)
-			break;
-		tr.leaf(tree, stack, work);
-		if (!tr.more)
-			break;
+	while (__ballot(tr.more)) {
+		if (tr.more)
+			tr.step(tree, stack, depth, work);
 	}
 	hit = tr.result();
 }

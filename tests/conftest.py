@@ -2,6 +2,8 @@ import os
 import sys
 
 import pytest
+import torch  # noqa: F401  loaded BEFORE libraytracer_amd.so: torch carries its own HIP runtime, and whichever
+#               runtime is loaded second in a process finds no GPU
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):

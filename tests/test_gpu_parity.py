@@ -305,3 +305,22 @@ def test_benchmark_size_properties(gpu):
     low = gpu.render_scene(psc, seed=7, samples_per_stream=16)[0].astype(np.float64)
     rmse = float(np.sqrt(np.mean((low - bgr.astype(np.float64)) ** 2)))
     assert rmse < 2.5, rmse                                    # noise of the 16-spp frame: ~1.5 expected
+
+
+def test_design_variants_return_the_same_bits(gpu):
+    """The measurement-only traversal variants (private-memory stack, division
+    box test, reference node layout) must agree with the production kernel."""
+    import torch
+    osc, psc = load_pair("dragon.txt")
+    gpu.upload(psc)
+    rr = np.concatenate([raygen.camera_grid(osc.camera(), 400, 400, step=2),
+                         raygen.random_rays(50000, (-0.6, -1.3, 0.2), (0.7, 1.4, 2.1), seed=9), raygen.axis_rays()])
+    want = gpu.trace_closest(rr)
+    dev = torch.device("cuda", 0)
+    rt = torch.from_numpy(np.ascontiguousarray(rr)).to(dev)
+    for variant in (0, 1, 2, 3):
+        ht = torch.zeros((rr.shape[0], 4), dtype=torch.float32, device=dev)
+        gpu.trace_variant_device(variant, rt.data_ptr(), rr.shape[0], ht.data_ptr())
+        got = ht.cpu().numpy()
+        assert np.array_equal(got[:, 0].view(np.int32), want["prim"]), variant
+        assert np.array_equal(got[:, 1].view(np.uint32), want["t"].view(np.uint32)), variant

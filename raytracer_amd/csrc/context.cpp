@@ -286,12 +286,7 @@ std::string flatten(const rta_scene_desc &d, Flattened &out)
 		out.pairs[p * 4 + 0] = make_float4(a[0], a[1], a[2], a[3]);
 		out.pairs[p * 4 + 1] = make_float4(a[4], a[5], b[0], b[1]);
 		out.pairs[p * 4 + 2] = make_float4(b[2], b[3], b[4], b[5]);
-		auto counted = [&](int32_t node) -> uint32_t {
-			if (d.node_count[node] <= 0)
-				return ref_of(node);
-			return kLeaf | ((uint32_t)(std::min(d.node_count[node], 128) - 1) << 24) | ((uint32_t)d.node_index[node] & 0xffffffu);
-		};
-		out.pairs[p * 4 + 3] = make_float4(as_float(ref_of(l)), as_float(ref_of(r)), as_float(counted(l)), as_float(counted(r)));
+		out.pairs[p * 4 + 3] = make_float4(as_float(ref_of(l)), as_float(ref_of(r)), 0.f, 0.f);
 	}
 
 	out.ref_nodes.resize((size_t)d.n_nodes * 2);
@@ -473,8 +468,8 @@ int rta_debug_trace_variant(rta_context *ctx, int variant, const float *rays, in
 		return rta_trace_closest(ctx, rays, n, hits, mem);
 	if (!ctx->have_scene)
 		return ctx->fail(RTA_E_NO_SCENE, "no scene uploaded");
-	if (variant < 1 || variant > 5 || n <= 0 || !rays || !hits || mem != RTA_MEM_DEVICE)
-		return ctx->fail(RTA_E_INVALID, "variants 1..3 take device-resident ray batches");
+	if (variant < 1 || variant > 4 || n <= 0 || !rays || !hits || mem != RTA_MEM_DEVICE)
+		return ctx->fail(RTA_E_INVALID, "variants 1..4 take device-resident ray batches");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	launch_variant(ctx->stream, variant, tree_of(ctx), ctx->ref_nodes.as<const float4>(), rays, (uint64_t)n, hits,
 	               ctx->stack_depth);

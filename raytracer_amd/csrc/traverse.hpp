@@ -179,14 +179,14 @@ RTA_DEV float test_box_tame(V3 lo, V3 hi, const Ray &r, V3 rcp, float max_t)
 // unit of work, either one inner-node visit (both child boxes) or one primitive
 // test, and leaves in `node` what the lane does next.
 //
-// `stack` points at the lane's column of an LDS array laid out [depth][kBlock],
+// `stack` points at the lane's column of an LDS array laid out [depth][STRIDE],
 // so consecutive lanes hit consecutive banks; upload guarantees the tree never
 // needs more than `depth` entries.  For ANY, `limit` is the distance bound and
 // the answer is prim >= 0.
 //
 // TAME_ONLY promises that every ray given to start() passes ray_is_tame() on a
 // tame tree; the kernel then carries no code for the division-based box test.
-template <bool ANY, bool COUNT, bool TAME_ONLY = false>
+template <bool ANY, bool COUNT, bool TAME_ONLY = false, int STRIDE = kBlock>
 struct Traversal {
 	Ray ray;
 	V3 rcp;              // correctly rounded 1/direction (only used when tame)
@@ -244,7 +244,7 @@ struct Traversal {
 			if (!(flags & kPrimLast))
 				node = node + 1;      // next primitive of the same leaf
 			else if (sp > 0)
-				node = stack[(--sp) * kBlock];
+				node = stack[(--sp) * STRIDE];
 			else
 				more = false;
 		} else {
@@ -280,13 +280,13 @@ struct Traversal {
 			if (hit_first) {
 				node = first;
 				if (hit_second && sp < depth) {      // sp == depth cannot happen on a validated tree
-					stack[sp * kBlock] = second;
+					stack[sp * STRIDE] = second;
 					sp++;
 				}
 			} else if (hit_second) {
 				node = second;
 			} else if (sp > 0) {
-				node = stack[(--sp) * kBlock];
+				node = stack[(--sp) * STRIDE];
 			} else {
 				more = false;
 			}

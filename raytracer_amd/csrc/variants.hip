@@ -9,6 +9,9 @@
 //   3  the reference's node array as it is (32-byte nodes, src/main.cpp:20-23):
 //      a visit loads the two children's records from index and index+1, the
 //      stack holds node numbers, and a popped node's (index, count) is re-read
+//   4  two nested loops per ray (walk inner nodes down to a leaf, then test all
+//      of the leaf's primitives) instead of one loop whose every trip is one
+//      node visit or one primitive test
 
 #include "kernels.hpp"
 #include "traverse.hpp"
@@ -17,88 +20,22 @@ namespace rta {
 
 namespace {
 
-template <bool FORCE_DIVISION>
-struct PrivateStackTraversal {
-	// same state machine as Traversal<false, false>, with the stack in a lane-private array
-	RTA_DEV static HitRec run(const DeviceTree &tree, const Ray &ray)
-	{
-		uint32_t stack[64];
-		const RaySigns sg = signs_of(ray);
-		const bool tame = !FORCE_DIVISION && tree.tame != 0 && ray_is_tame(ray);
-		const V3 rcp = mk(1.f / ray.d.x, 1.f / ray.d.y, 1.f / ray.d.z);
-		float best = FLT_MAX, bu = 0, bv = 0;
-		int32_t prim = -1;
-		uint32_t node = tree.root;
-		int sp = 0;
-		bool more = true;
-		while (more) {
-			while (more && !(node & kLeafBit)) {
-				const float4 *rec = tree.pairs + 4 * (size_t)node;
-				const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
-				const uint32_t ref1 = __float_as_uint(q3.x), ref2 = __float_as_uint(q3.y);
-				float d1, d2;
-				if (tame) {
-					d1 = test_box_tame(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), ray, rcp, best);
-					d2 = test_box_tame(mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w), ray, rcp, best);
-				} else {
-					d1 = test_box(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), ray, sg, best);
-					d2 = test_box(mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w), ray, sg, best);
-				}
-				const bool one_near = d1 < d2;
-				const uint32_t first = one_near ? ref1 : ref2, second = one_near ? ref2 : ref1;
-				const bool hit_first = (one_near ? d1 : d2) < FLT_MAX, hit_second = (one_near ? d2 : d1) < FLT_MAX;
-				if (hit_first) {
-					node = first;
-					if (hit_second && sp < 64)
-						stack[sp++] = second;
-				} else if (hit_second) {
-					node = second;
-				} else if (sp > 0) {
-					node = stack[--sp];
-				} else {
-					more = false;
-				}
-			}
-			if (!more)
-				break;
-			uint32_t i = node & ~kLeafBit;
-			for (;;) {
-				const float4 p0 = tree.prims[3 * (size_t)i], p1 = tree.prims[3 * (size_t)i + 1];
-				const uint32_t flags = __float_as_uint(p0.w);
-				float t, tu = 0, tv = 0;
-				if (flags & kPrimSphere) {
-					t = test_sphere(mk(p0.x, p0.y, p0.z), p1.x, ray);
-				} else {
-					const float4 p2 = tree.prims[3 * (size_t)i + 2];
-					t = test_triangle(mk(p0.x, p0.y, p0.z), mk(p1.x, p1.y, p1.z), mk(p2.x, p2.y, p2.z), ray, tu, tv);
-				}
-				if (t < best) {
-					best = t;
-					prim = (int32_t)i;
-					bu = tu;
-					bv = tv;
-				}
-				if (flags & kPrimLast)
-					break;
-				i++;
-			}
-			if (sp > 0)
-				node = stack[--sp];
-			else
-				more = false;
-		}
-		return HitRec{prim, best, bu, bv};
-	}
-};
-
 __global__ __launch_bounds__(kBlock) void k_variant_private_stack(const DeviceTree tree, const float *rays, uint64_t n,
                                                                   rta_hit *hits)
 {
 	const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
 	if (i >= n)
 		return;
+	uint32_t stack[64];
 	const float *r = rays + i * 6;
-	const HitRec h = PrivateStackTraversal<false>::run(tree, Ray{mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5])});
+	Traversal<false, false, false, 1> tr;
+	WorkCount wc = {0, 0, 0};
+	tr.start(tree, Ray{mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5])}, FLT_MAX);
+	while (__ballot(tr.more)) {
+		if (tr.more)
+			tr.step(tree, stack, 64, wc);
+	}
+	const HitRec h = tr.result();
 	hits[i] = rta_hit{h.prim, h.t, h.u, h.v};
 }
 
@@ -193,10 +130,11 @@ __global__ __launch_bounds__(kBlock) void k_variant_reference_nodes(const Device
 	hits[i] = rta_hit{prim, best, bu, bv};
 }
 
-// Production records and ref stack, but ONE loop that handles a leaf or an inner
-// node per iteration instead of the two-phase descend/leaf structure.
-__global__ __launch_bounds__(kBlock) void k_variant_single_loop(const DeviceTree tree, const float *rays, uint64_t n,
-                                                                rta_hit *hits, const int depth)
+// Production records and stack, but the ray walks inner nodes until it holds a
+// leaf and then tests the whole leaf: in a wave, every lane waits for the
+// slowest lane of each of the two inner loops.
+__global__ __launch_bounds__(kBlock) void k_variant_nested_loops(const DeviceTree tree, const float *rays, uint64_t n,
+                                                                 rta_hit *hits, const int depth)
 {
 	extern __shared__ uint32_t lds_stack[];
 	uint32_t *stack = lds_stack + threadIdx.x;
@@ -212,33 +150,9 @@ __global__ __launch_bounds__(kBlock) void k_variant_single_loop(const DeviceTree
 	int32_t prim = -1;
 	uint32_t node = tree.root;
 	int sp = 0;
-	for (;;) {
-		if (node & kLeafBit) {
-			uint32_t k = node & ~kLeafBit;
-			for (;;) {
-				const float4 p0 = tree.prims[3 * (size_t)k], p1 = tree.prims[3 * (size_t)k + 1];
-				const uint32_t flags = __float_as_uint(p0.w);
-				float t, tu = 0, tv = 0;
-				if (flags & kPrimSphere) {
-					t = test_sphere(mk(p0.x, p0.y, p0.z), p1.x, ray);
-				} else {
-					const float4 p2 = tree.prims[3 * (size_t)k + 2];
-					t = test_triangle(mk(p0.x, p0.y, p0.z), mk(p1.x, p1.y, p1.z), mk(p2.x, p2.y, p2.z), ray, tu, tv);
-				}
-				if (t < best) {
-					best = t;
-					prim = (int32_t)k;
-					bu = tu;
-					bv = tv;
-				}
-				if (flags & kPrimLast)
-					break;
-				k++;
-			}
-			if (sp == 0)
-				break;
-			node = stack[(--sp) * kBlock];
-		} else {
+	bool more = true;
+	while (more) {
+		while (more && !(node & kLeafBit)) {
 			const float4 *rec = tree.pairs + 4 * (size_t)node;
 			const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
 			const uint32_t ref1 = __float_as_uint(q3.x), ref2 = __float_as_uint(q3.y);
@@ -259,88 +173,39 @@ __global__ __launch_bounds__(kBlock) void k_variant_single_loop(const DeviceTree
 					stack[(sp++) * kBlock] = second;
 			} else if (hit_second) {
 				node = second;
-			} else {
-				if (sp == 0)
-					break;
+			} else if (sp > 0) {
 				node = stack[(--sp) * kBlock];
+			} else {
+				more = false;
 			}
 		}
-	}
-	hits[i] = rta_hit{prim, best, bu, bv};
-}
-
-// Experiment: pair records for the boxes, but leaves iterate over a primitive
-// COUNT known before the loop (taken from the last-in-leaf flags by a cheap
-// pre-scan of the first words), so that all the leaf's loads can be in flight
-// together.
-__global__ __launch_bounds__(kBlock) void k_variant_counted_leaf(const DeviceTree tree, const float *rays, uint64_t n,
-                                                                 rta_hit *hits, const int depth)
-{
-	extern __shared__ uint32_t lds_stack[];
-	uint32_t *stack = lds_stack + threadIdx.x;
-	const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-	if (i >= n)
-		return;
-	const float *r = rays + i * 6;
-	const Ray ray = {mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5])};
-	const bool tame = tree.tame != 0 && ray_is_tame(ray);
-	const RaySigns sg = signs_of(ray);
-	const V3 rcp = mk(1.f / ray.d.x, 1.f / ray.d.y, 1.f / ray.d.z);
-	float best = FLT_MAX, bu = 0, bv = 0;
-	int32_t prim = -1;
-	uint32_t node = tree.root;
-	int sp = 0;
-	for (;;) {
-		if (node & kLeafBit) {
-			const uint32_t first = node & 0x00ffffffu, count = ((node >> 24) & 0x7fu) + 1;
-			for (uint32_t k = first; k < first + count; k++) {
-				const float4 p0 = tree.prims[3 * (size_t)k], p1 = tree.prims[3 * (size_t)k + 1];
-				const uint32_t flags = __float_as_uint(p0.w);
-				float t, tu = 0, tv = 0;
-				if (flags & kPrimSphere) {
-					t = test_sphere(mk(p0.x, p0.y, p0.z), p1.x, ray);
-				} else {
-					const float4 p2 = tree.prims[3 * (size_t)k + 2];
-					t = test_triangle(mk(p0.x, p0.y, p0.z), mk(p1.x, p1.y, p1.z), mk(p2.x, p2.y, p2.z), ray, tu, tv);
-				}
-				if (t < best) {
-					best = t;
-					prim = (int32_t)k;
-					bu = tu;
-					bv = tv;
-				}
+		if (!more)
+			break;
+		uint32_t k = node & ~kLeafBit;
+		for (;;) {
+			const float4 p0 = tree.prims[3 * (size_t)k], p1 = tree.prims[3 * (size_t)k + 1];
+			const uint32_t flags = __float_as_uint(p0.w);
+			float t, tu = 0, tv = 0;
+			if (flags & kPrimSphere) {
+				t = test_sphere(mk(p0.x, p0.y, p0.z), p1.x, ray);
+			} else {
+				const float4 p2 = tree.prims[3 * (size_t)k + 2];
+				t = test_triangle(mk(p0.x, p0.y, p0.z), mk(p1.x, p1.y, p1.z), mk(p2.x, p2.y, p2.z), ray, tu, tv);
 			}
-			if (sp == 0)
+			if (t < best) {
+				best = t;
+				prim = (int32_t)k;
+				bu = tu;
+				bv = tv;
+			}
+			if (flags & kPrimLast)
 				break;
-			node = stack[(--sp) * kBlock];
-		} else {
-			const float4 *rec = tree.pairs + 4 * (size_t)node;
-			const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
-			// q3.z / q3.w: the children's refs with the leaf size folded in (see launch_variant)
-			const uint32_t ref1 = __float_as_uint(q3.z), ref2 = __float_as_uint(q3.w);
-			float d1, d2;
-			if (tame) {
-				d1 = test_box_tame(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), ray, rcp, best);
-				d2 = test_box_tame(mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w), ray, rcp, best);
-			} else {
-				d1 = test_box(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), ray, sg, best);
-				d2 = test_box(mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w), ray, sg, best);
-			}
-			const bool one_near = d1 < d2;
-			const uint32_t first = one_near ? ref1 : ref2, second = one_near ? ref2 : ref1;
-			const bool hit_first = (one_near ? d1 : d2) < FLT_MAX, hit_second = (one_near ? d2 : d1) < FLT_MAX;
-			if (hit_first) {
-				node = first;
-				if (hit_second && sp < depth)
-					stack[(sp++) * kBlock] = second;
-			} else if (hit_second) {
-				node = second;
-			} else {
-				if (sp == 0)
-					break;
-				node = stack[(--sp) * kBlock];
-			}
+			k++;
 		}
+		if (sp > 0)
+			node = stack[(--sp) * kBlock];
+		else
+			more = false;
 	}
 	hits[i] = rta_hit{prim, best, bu, bv};
 }
@@ -360,10 +225,7 @@ void launch_variant(hipStream_t s, int variant, const TreeRef &tree, const float
 		hipLaunchKernelGGL(k_variant_division, dim3(blocks), dim3(kBlock), lds, s, tree, rays, n, hits, depth);
 		break;
 	case 4:
-		hipLaunchKernelGGL(k_variant_single_loop, dim3(blocks), dim3(kBlock), lds, s, tree, rays, n, hits, depth);
-		break;
-	case 5:
-		hipLaunchKernelGGL(k_variant_counted_leaf, dim3(blocks), dim3(kBlock), lds, s, tree, rays, n, hits, depth);
+		hipLaunchKernelGGL(k_variant_nested_loops, dim3(blocks), dim3(kBlock), lds, s, tree, rays, n, hits, depth);
 		break;
 	default:
 		hipLaunchKernelGGL(k_variant_reference_nodes, dim3(blocks), dim3(kBlock), lds, s, tree, reference_nodes, rays, n,

@@ -17,12 +17,11 @@ import torch
 import rays as raygen
 import raytracer_amd as rta
 
-NAMES = {0: "production (64 B pair records, LDS stack, reciprocal box test)",
+NAMES = {0: "production (64 B pair records, LDS stack, reciprocal box test, one loop)",
          1: "stack in private memory",
          2: "division-based box test",
          3: "reference 32 B nodes + node-number stack",
-         4: "production records, one loop (leaf or inner node per iteration)",
-         5: "production records, one loop, leaf size known before the leaf loop"}
+         4: "nested loops (inner nodes to a leaf, then the whole leaf)"}
 
 
 def main():
@@ -50,7 +49,7 @@ def main():
         rt = torch.from_numpy(np.ascontiguousarray(rr)).to(dev)
         n = rr.shape[0]
         base = None
-        for variant in (0, 1, 2, 3, 4, 5):
+        for variant in (0, 1, 2, 3, 4):
             ht = torch.zeros((n, 4), dtype=torch.float32, device=dev)
             ctx.trace_variant_device(variant, rt.data_ptr(), n, ht.data_ptr())
             best = 1e9

@@ -75,7 +75,7 @@ struct rta_context {
 	int32_t n_prims = 0, n_lights = 0;
 
 	// wavefront workspace
-	DeviceBuffer ray0, ray1, hit, thr, col, acc, meta, q_ray, shadow, partial, pixels, frame, bgr, counters;
+	DeviceBuffer ray0, ray1, hit, thr, col, rng, acc, meta, q_ray, shadow, partial, pixels, frame, bgr, counters;
 	DeviceBuffer io_a, io_b, io_c;       // staging for host-pointer calls
 	Counters *host_counters = nullptr;    // pinned, kMaxGroups entries
 
@@ -614,6 +614,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	HIP_TRY(ctx, ctx->hit.reserve(S * 16));
 	HIP_TRY(ctx, ctx->thr.reserve(S * 16));
 	HIP_TRY(ctx, ctx->col.reserve(S * 16));
+	HIP_TRY(ctx, ctx->rng.reserve(S * 4));
 	HIP_TRY(ctx, ctx->acc.reserve(S * 16));
 	HIP_TRY(ctx, ctx->meta.reserve(S * 16));
 	// per group: 2 parities x kRayKinds kinds x kShards sub-queues, each able to take
@@ -680,6 +681,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		a.hit = ctx->hit.as<float4>() + off;
 		a.thr = ctx->thr.as<float4>() + off;
 		a.col = ctx->col.as<float4>() + off;
+		a.rng = ctx->rng.as<uint32_t>() + off;
 		a.acc = ctx->acc.as<float4>() + off;
 		a.meta = ctx->meta.as<uint4>() + off;
 		a.shadow = ctx->shadow.as<float4>() ? ctx->shadow.as<float4>() + 3 * off : nullptr;
@@ -760,11 +762,12 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 			for (int g = 0; g < groups; g++) {
 				const RenderArgs &a = ga[g];
 				const int par = (int)(steps & 1);
-				launch_generate(gs[g], a, par);
-				HIP_TRY_R(timed(gs[g], 0, [&] { launch_intersect(gs[g], a, par, ctx->stack_depth, count_work); }));
-				launch_shade(gs[g], a, par ^ 1);
+				// advance queues the step's rays; shadow comes before intersect, whose
+				// first workgroup empties the occlusion queue for the next step
+				launch_advance(gs[g], a, par);
 				if (lights)
 					HIP_TRY_R(timed(gs[g], 1, [&] { launch_shadow(gs[g], a, group_slots, ctx->stack_depth, count_work); }));
+				HIP_TRY_R(timed(gs[g], 0, [&] { launch_intersect(gs[g], a, par, ctx->stack_depth, count_work); }));
 			}
 			steps++;
 		}

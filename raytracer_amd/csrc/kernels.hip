@@ -1,14 +1,15 @@
 // HIP kernels of the wavefront path tracer (gfx950, wave64) and their
 // launchers.  The reference's per-pixel loop (src/main.cpp:657-714) becomes
-// four kernels per wavefront step over a fixed pool of path slots:
+// three kernels per wavefront step over a fixed pool of path slots:
 //
-//   generate   retire finished samples into their block sum, hand out the next
-//              sample block, draw the camera ray (src/main.cpp:663-687)
-//   intersect  closest hit (src/main.cpp:332-422)
-//   shade      one bounce of RayTrace (src/main.cpp:507-589): emission, light
-//              sampling, BSDF sampling, Russian roulette
+//   advance    everything between two traversals of a path: shade the hit (one
+//              bounce of RayTrace, src/main.cpp:507-589: emission, light
+//              sampling, BSDF sampling, Russian roulette), retire a finished
+//              sample into its block sum, hand out the next sample block, draw
+//              the camera ray (src/main.cpp:663-687)
 //   shadow     occlusion query for the sampled light (src/main.cpp:424-478) and
 //              the deferred radiance add
+//   intersect  closest hit (src/main.cpp:332-422)
 //
 // followed once by block-sum accumulation and the tone-mapping resolve
 // (src/main.cpp:692-706).
@@ -23,17 +24,17 @@
 // the lanes of the intersect kernel on the same side of the tree.  Results
 // depend only on (seed, pixel, block), never on this schedule.
 //
-// Lane i of every generate and shade launch works on slot i, so the slot state
-// (seven 16-byte arrays) is read and written fully coalesced.  Rays reach the
-// traversal kernels through queues compacted with a wave64 ballot + prefix
-// count and one atomic per wave: generate queues the slots of fresh camera rays
-// (coherent: a wave's rays cross one tile), shade queues the slots of
-// continuing paths (incoherent bounce rays) separately, and queues occlusion
-// queries with their payload.  Keeping the two kinds of closest-hit rays in
-// different queues is the divergence control: a traversal wave then holds rays
-// of one kind, whose node-visit counts differ far less than across kinds.  Each
-// queue is cut into kShards sub-queues (picked by workgroup) so that the
-// appending atomics spread over many addresses.
+// Lane i of every advance launch works on slot i, so the slot state (16-byte
+// arrays, read and written only where a path's stage needs them) moves fully
+// coalesced.  Rays reach the traversal kernels through queues compacted with a
+// wave64 ballot + prefix count and one atomic per wave: the slots of fresh
+// camera rays (coherent: a wave's rays cross one tile) and of continuing paths
+// (incoherent bounce rays) go to different queues, occlusion queries to a third
+// with their payload.  Keeping the two kinds of closest-hit rays apart is the
+// divergence control: a traversal wave then holds rays of one kind, whose
+// node-visit counts differ far less than across kinds.  Each queue is cut into
+// kShards sub-queues (picked by workgroup) so that the appending atomics spread
+// over many addresses.
 
 #include "kernels.hpp"
 
@@ -47,7 +48,7 @@ namespace {
 // slot states kept in the bounce word (ray1.w): a bounce number, or
 constexpr uint32_t kWaiting = 0xfffffffdu;     // through with its blocks; waits for the wave's next tile
 constexpr uint32_t kRetired = 0xfffffffeu;     // no work left for this wave
-constexpr uint32_t kEnded = 0xffffffffu;       // path finished; generate takes over
+constexpr uint32_t kEnded = 0xffffffffu;       // path finished, its occlusion query pending; retired by the next pass
 // kinds of closest-hit rays, queued apart; kOddRays are the (rare) rays whose
 // box tests need the division-based form (see ray_is_tame), of either origin
 constexpr int kCameraRays = 0, kBounceRays = 1, kOddRays = 2;
@@ -102,96 +103,10 @@ RTA_DEV void ray_queue_push(const RenderArgs &a, int par, int kind, bool pred, u
 	}
 }
 
-// ------------------------------------------------------------------ generate
-
-RTA_DEV Ray camera_ray(const RenderArgs &a, uint32_t slot, uint32_t pixel, uint32_t rng, uint32_t done);
-
-// `par`: parity of the step whose intersect launch will trace the new rays.
-__global__ __launch_bounds__(kBlock) void k_generate(const RenderArgs a, const int par)
-{
-	const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
-	if (slot >= a.n_slots)        // n_slots is a multiple of 64: whole waves leave together
-		return;
-	const uint32_t lane = threadIdx.x & 63;
-	float4 R1 = a.ray1[slot];
-	uint32_t state = __float_as_uint(R1.w);
-	if (__ballot(state >= kWaiting && state != kRetired) == 0)
-		return;                   // every lane is mid-path or retired: nothing to generate
-
-	uint4 M = a.meta[slot];       // pixel, current block, end of the block run, index in the padded pixel list
-	float4 A = make_float4(0.f, 0.f, 0.f, 0.f);
-	uint32_t rng = 0, done = 0;
-	bool need_ray = false;
-
-	if (state == kEnded) {
-		// the finished sample joins its block sum (src/main.cpp:689)
-		A = a.acc[slot];
-		const float4 C = a.col[slot];
-		rng = __float_as_uint(a.thr[slot].w);
-		done = __float_as_uint(C.w) + 1;
-		A.x += C.x;
-		A.y += C.y;
-		A.z += C.z;
-		const uint32_t first = M.y * a.sps;
-		const uint32_t len = a.spp - first < a.sps ? a.spp - first : a.sps;
-		need_ray = true;
-		if (done >= len) {
-			a.partial[(size_t)M.y * a.n_pad + M.w] = A;
-			A = make_float4(0.f, 0.f, 0.f, 0.f);
-			done = 0;
-			M.y++;
-			if (M.y >= M.z) {
-				state = kWaiting;
-				need_ray = false;
-			} else {
-				rng = stream_seed(a.seed, M.x, M.y);
-			}
-		}
-	}
-
-	// the whole wave is through: draw the next (tile, block run)
-	if (__ballot(state == kWaiting) == ~0ull) {
-		uint32_t got = 0;
-		if (lane == 0)
-			got = atomicAdd(a.next_item, 1u);
-		got = __shfl(got, 0);
-		if (got < a.n_items) {
-			const uint32_t run = got / a.n_tiles, tile = got - run * a.n_tiles;
-			const uint32_t padded = tile * 64 + lane;
-			const int32_t pixel = a.pixels[padded];
-			if (pixel >= 0) {
-				M.x = (uint32_t)pixel;
-				M.y = run * a.run_blocks;
-				M.z = M.y + a.run_blocks < a.n_blocks ? M.y + a.run_blocks : a.n_blocks;
-				M.w = padded;
-				rng = stream_seed(a.seed, M.x, M.y);
-				A = make_float4(0.f, 0.f, 0.f, 0.f);
-				done = 0;
-				need_ray = true;
-			}
-		} else {
-			state = kRetired;
-			if (lane == 0)
-				atomicSub(&a.cnt->live, 1u);
-		}
-	}
-
-	Ray ray = {mk(0, 0, 0), mk(1, 1, 1)};
-	if (!need_ray) {
-		if (state != __float_as_uint(R1.w)) {
-			R1.w = __uint_as_float(state);
-			a.ray1[slot] = R1;
-		}
-	} else {
-		a.meta[slot] = M;
-		a.acc[slot] = A;
-		ray = camera_ray(a, slot, M.x, rng, done);
-	}
-	ray_queue_push(a, par, kCameraRays, need_ray, slot, ray);
-}
+// ------------------------------------------------------------------ advance
 
 // One camera sample of pixel `pixel` (src/main.cpp:663-687) written into `slot`.
-RTA_DEV Ray camera_ray(const RenderArgs &a, uint32_t slot, uint32_t pixel, uint32_t rng, uint32_t done)
+RTA_DEV Ray camera_ray(const RenderArgs &a, uint32_t slot, uint32_t pixel, uint32_t &rng)
 {
 	const uint32_t pu = pixel % a.width, pv = pixel / a.width;
 	const V3 cam_o = mk(a.cam.origin[0], a.cam.origin[1], a.cam.origin[2]);
@@ -225,109 +140,58 @@ RTA_DEV Ray camera_ray(const RenderArgs &a, uint32_t slot, uint32_t pixel, uint3
 	const V3 dir = unit(target - origin);
 	a.ray0[slot] = make_float4(origin.x, origin.y, origin.z, dir.x);
 	a.ray1[slot] = make_float4(dir.y, dir.z, 1.f, __uint_as_float(0u));     // bsdf_pdf = 1, bounce 0
-	a.thr[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(rng));
-	a.col[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(done));
 	return Ray{origin, dir};
 }
 
-// ------------------------------------------------------------------ intersect
-
-// Housekeeping done by the first workgroup of the first traversal launch of a
-// step: count the step's rays, empty the queues the previous step consumed,
-// empty the occlusion queue.
-RTA_DEV void step_housekeeping(const RenderArgs &a, int par)
-{
-	if (threadIdx.x < kRayKinds * kShards) {
-		const uint32_t n = a.cnt->n_ray[ray_queue_index(par, 0, 0) + threadIdx.x];
-		if (n)
-			atomicAdd(&a.cnt->rays, (unsigned long long)n);
-		a.cnt->n_ray[ray_queue_index(par ^ 1, 0, 0) + threadIdx.x] = 0;
-	}
-	if (threadIdx.x == 0)
-		a.cnt->n_shadow = 0;
-}
-
-// Camera and bounce rays.  Grid: 2 kinds x kShards sub-queues x
-// (shard_cap / kBlock) workgroups, shards innermost so that the first
-// workgroups of all shards start together; a workgroup whose part of its
-// sub-queue is empty leaves at once.
-template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_intersect(const RenderArgs a, const int par, const int depth)
-{
-	extern __shared__ uint32_t lds_stack[];
-	const uint32_t per_kind = kShards * (a.shard_cap / kBlock);
-	const uint32_t kind = blockIdx.x / per_kind, rem = blockIdx.x - kind * per_kind;
-	const uint32_t shard = rem % kShards, part = rem / kShards;
-	const uint32_t q = ray_queue_index(par, (int)kind, shard);
-	const uint32_t total = a.cnt->n_ray[q];
-	if (blockIdx.x == 0)
-		step_housekeeping(a, par);
-	const uint32_t i = part * kBlock + threadIdx.x;
-	WorkCount wc = {0, 0, 0};
-	if (i < total) {
-		const uint32_t slot = a.q_ray[(size_t)q * a.shard_cap + i];
-		const float4 r0 = a.ray0[slot], r1 = a.ray1[slot];
-		Ray ray = {mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y)};
-		HitRec h;
-		traverse_dyn<false, COUNT, true>(a.tree, ray, FLT_MAX, lds_stack + threadIdx.x, depth, h, wc);
-		a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
-	}
-	if (COUNT)
-		count_flush(a.cnt, wc);
-}
-
-// The rays that need the division-based box test.  Any grid that is a multiple
-// of kShards works: the workgroups of a shard stride over its sub-queue.
-template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_intersect_odd(const RenderArgs a, const int par, const int depth)
-{
-	extern __shared__ uint32_t lds_stack[];
-	const uint32_t shard = blockIdx.x % kShards, part = blockIdx.x / kShards, parts = gridDim.x / kShards;
-	const uint32_t q = ray_queue_index(par, kOddRays, shard);
-	const uint32_t total = a.cnt->n_ray[q];
-	WorkCount wc = {0, 0, 0};
-	for (uint32_t i = part * kBlock + threadIdx.x; i < total; i += parts * kBlock) {
-		const uint32_t slot = a.q_ray[(size_t)q * a.shard_cap + i];
-		const float4 r0 = a.ray0[slot], r1 = a.ray1[slot];
-		Ray ray = {mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y)};
-		HitRec h;
-		traverse_dyn<false, COUNT, false>(a.tree, ray, FLT_MAX, lds_stack + threadIdx.x, depth, h, wc);
-		a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
-	}
-	if (COUNT)
-		count_flush(a.cnt, wc);
-}
-
-// ------------------------------------------------------------------ shade
-
-// `par`: parity of the NEXT step, whose intersect launch traces the bounce rays.
-__global__ __launch_bounds__(kBlock) void k_shade(const RenderArgs a, const int par)
+// Everything between two traversals of a slot, in one pass over the slot state:
+//
+//   shade     one bounce of RayTrace on the hit the traversal left
+//             (src/main.cpp:507-589);
+//   retire    a finished sample joins its block sum (src/main.cpp:689), a
+//             finished block is written out, a wave whose lanes are all through
+//             draws its next (tile, block run);
+//   generate  the next sample's camera ray (src/main.cpp:663-687).
+//
+// A path in its first segment has throughput 1 and radiance 0 by definition, so
+// neither array is read for it, and a sample that ends in the pass it was shaded
+// in never writes them.  `par`: parity of the step whose intersect launch traces
+// the rays queued here.
+__global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const int par)
 {
 	const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
-	bool want_shadow = false, alive = false;
-	Ray bounce_ray = {mk(0, 0, 0), mk(1, 1, 1)};
-	V3 sh_o = mk(0, 0, 0), sh_d = mk(0, 0, 0), sh_c = mk(0, 0, 0);
-	float sh_dist = 0;
+	const uint32_t lane = threadIdx.x & 63;
 	float4 r1 = make_float4(0.f, 0.f, 0.f, __uint_as_float(kRetired));
 	if (slot < a.n_slots)
 		r1 = a.ray1[slot];
+	uint32_t state = __float_as_uint(r1.w);
+	if (__ballot(state != kRetired) == 0)
+		return;                   // whole waves leave together
 
-	if (__float_as_uint(r1.w) < kWaiting) {
-		const float4 r0 = a.ray0[slot];
+	bool want_shadow = false, alive = false, ended = false;
+	Ray next_ray = {mk(0, 0, 0), mk(1, 1, 1)};
+	V3 sh_o = mk(0, 0, 0), sh_d = mk(0, 0, 0), sh_c = mk(0, 0, 0);
+	float sh_dist = 0;
+	V3 color = mk(0, 0, 0);
+	uint32_t rng = 0;
+
+	if (state < kWaiting) {
+		const uint32_t bounce = state;
 		const float4 H = a.hit[slot];
-		float4 T = a.thr[slot];
-		float4 C = a.col[slot];
-		const Ray ray = {mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y)};
-		const float prev_pdf = r1.z;
-		const uint32_t bounce = __float_as_uint(r1.w);
-		uint32_t rng = __float_as_uint(T.w);
-		V3 thr = xyz(T), color = xyz(C);
+		rng = a.rng[slot];
+		V3 thr = mk(1, 1, 1);
+		if (bounce > 0) {
+			thr = xyz(a.thr[slot]);
+			color = xyz(a.col[slot]);
+		}
 		const int32_t prim = __float_as_int(H.x);
 
 		if (prim < 0) {
 			// src/main.cpp:511-514
 			color = color + thr * mk(a.sky[0], a.sky[1], a.sky[2]);
 		} else {
+			const float4 r0 = a.ray0[slot];
+			const Ray ray = {mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y)};
+			const float prev_pdf = r1.z;
 			const float t = H.y, bu = H.z, bv = H.w;
 			const float4 s0 = a.shade_prims[3 * (size_t)prim];
 			const float4 s1 = a.shade_prims[3 * (size_t)prim + 1];
@@ -408,8 +272,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(const RenderArgs a, const int 
 			}
 
 			// src/main.cpp:573-588
-			const BsdfSample s = sample_bsdf(v, mat, rng);
-			thr = thr * (s.f / s.pdf);
+			const BsdfSample bs = sample_bsdf(v, mat, rng);
+			thr = thr * (bs.f / bs.pdf);
 			bool stop = false;
 			if (bounce > 3) {
 				const float p = greater(thr.x, greater(thr.y, thr.z));
@@ -419,20 +283,100 @@ __global__ __launch_bounds__(kBlock) void k_shade(const RenderArgs a, const int 
 					thr = thr / p;
 			}
 			if (!stop && bounce + 1 < (uint32_t)a.max_bounces) {
-				const V3 nd = to_world(fr, s.l);
+				const V3 nd = to_world(fr, bs.l);
 				a.ray0[slot] = make_float4(point.x, point.y, point.z, nd.x);
-				a.ray1[slot] = make_float4(nd.y, nd.z, s.pdf, __uint_as_float(bounce + 1));
-				bounce_ray = Ray{point, nd};
+				a.ray1[slot] = make_float4(nd.y, nd.z, bs.pdf, __uint_as_float(bounce + 1));
+				a.thr[slot] = f4(thr, 0.f);
+				next_ray = Ray{point, nd};
 				alive = true;
 			}
 		}
-		if (!alive)
-			a.ray1[slot] = make_float4(r1.x, r1.y, r1.z, __uint_as_float(kEnded));
-		a.thr[slot] = f4u(thr, rng);
-		a.col[slot] = make_float4(color.x, color.y, color.z, C.w);
+		if (alive || want_shadow) {
+			// the radiance so far is needed again: by the next bounce, or by the
+			// occlusion query that may add the light's share to it
+			a.col[slot] = f4(color, 0.f);
+			if (!alive)
+				state = kEnded;         // retired by the next pass, after k_shadow has run
+			a.rng[slot] = rng;
+		} else {
+			ended = true;
+		}
+	} else if (state == kEnded) {
+		color = xyz(a.col[slot]);
+		rng = a.rng[slot];
+		ended = true;
 	}
 
-	ray_queue_push(a, par, kBounceRays, alive, slot, bounce_ray);
+	uint4 M = make_uint4(0u, 0u, 0u, 0u);     // pixel, current block, end of the block run, index in the padded pixel list
+	float4 A = make_float4(0.f, 0.f, 0.f, 0.f);     // block sum, samples finished in the block
+	bool need_ray = false;
+	if (ended) {
+		// the finished sample joins its block sum (src/main.cpp:689)
+		M = a.meta[slot];
+		A = a.acc[slot];
+		uint32_t done = __float_as_uint(A.w) + 1;
+		A.x += color.x;
+		A.y += color.y;
+		A.z += color.z;
+		const uint32_t first = M.y * a.sps;
+		const uint32_t len = a.spp - first < a.sps ? a.spp - first : a.sps;
+		need_ray = true;
+		if (done >= len) {
+			a.partial[(size_t)M.y * a.n_pad + M.w] = make_float4(A.x, A.y, A.z, 0.f);
+			A = make_float4(0.f, 0.f, 0.f, 0.f);
+			done = 0;
+			M.y++;
+			if (M.y >= M.z) {
+				state = kWaiting;
+				need_ray = false;
+			} else {
+				rng = stream_seed(a.seed, M.x, M.y);
+				a.meta[slot] = M;
+			}
+		}
+		A.w = __uint_as_float(done);
+	}
+
+	// the whole wave is through: draw the next (tile, block run)
+	if (__ballot(state == kWaiting) == ~0ull) {
+		uint32_t got = 0;
+		if (lane == 0)
+			got = atomicAdd(a.next_item, 1u);
+		got = __shfl(got, 0);
+		if (got < a.n_items) {
+			const uint32_t run = got / a.n_tiles, tile = got - run * a.n_tiles;
+			const uint32_t padded = tile * 64 + lane;
+			const int32_t pixel = a.pixels[padded];
+			if (pixel >= 0) {
+				M.x = (uint32_t)pixel;
+				M.y = run * a.run_blocks;
+				M.z = M.y + a.run_blocks < a.n_blocks ? M.y + a.run_blocks : a.n_blocks;
+				M.w = padded;
+				a.meta[slot] = M;
+				rng = stream_seed(a.seed, M.x, M.y);
+				A = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
+				need_ray = true;
+			}
+		} else {
+			state = kRetired;
+			if (lane == 0)
+				atomicSub(&a.cnt->live, 1u);
+		}
+	}
+
+	if (need_ray) {
+		a.acc[slot] = A;
+		next_ray = camera_ray(a, slot, M.x, rng);
+		a.rng[slot] = rng;
+	} else if (state >= kWaiting && state != __float_as_uint(r1.w)) {
+		a.ray1[slot] = make_float4(r1.x, r1.y, r1.z, __uint_as_float(state));
+	}
+
+	// camera rays are coherent (a wave's rays cross one tile), bounce rays are not:
+	// they are queued apart so that a traversal wave holds rays of one kind
+	ray_queue_push(a, par, kCameraRays, need_ray, slot, next_ray);
+	if (__ballot(alive))
+		ray_queue_push(a, par, kBounceRays, alive, slot, next_ray);
 	if (a.n_lights > 0) {
 		const uint32_t at_sh = queue_push(want_shadow, &a.cnt->n_shadow);
 		if (want_shadow) {
@@ -442,6 +386,74 @@ __global__ __launch_bounds__(kBlock) void k_shade(const RenderArgs a, const int 
 			e[2] = f4(sh_c, 0.f);
 		}
 	}
+}
+
+// ------------------------------------------------------------------ intersect
+
+// Housekeeping done by the first workgroup of the first traversal launch of a
+// step: count the step's rays, empty the queues the previous step consumed,
+// empty the occlusion queue.
+RTA_DEV void step_housekeeping(const RenderArgs &a, int par)
+{
+	if (threadIdx.x < kRayKinds * kShards) {
+		const uint32_t n = a.cnt->n_ray[ray_queue_index(par, 0, 0) + threadIdx.x];
+		if (n)
+			atomicAdd(&a.cnt->rays, (unsigned long long)n);
+		a.cnt->n_ray[ray_queue_index(par ^ 1, 0, 0) + threadIdx.x] = 0;
+	}
+	if (threadIdx.x == 0)
+		a.cnt->n_shadow = 0;
+}
+
+// Camera and bounce rays.  Grid: 2 kinds x kShards sub-queues x
+// (shard_cap / kBlock) workgroups, shards innermost so that the first
+// workgroups of all shards start together; a workgroup whose part of its
+// sub-queue is empty leaves at once.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_intersect(const RenderArgs a, const int par, const int depth)
+{
+	extern __shared__ uint32_t lds_stack[];
+	const uint32_t per_kind = kShards * (a.shard_cap / kBlock);
+	const uint32_t kind = blockIdx.x / per_kind, rem = blockIdx.x - kind * per_kind;
+	const uint32_t shard = rem % kShards, part = rem / kShards;
+	const uint32_t q = ray_queue_index(par, (int)kind, shard);
+	const uint32_t total = a.cnt->n_ray[q];
+	if (blockIdx.x == 0)
+		step_housekeeping(a, par);
+	const uint32_t i = part * kBlock + threadIdx.x;
+	WorkCount wc = {0, 0, 0};
+	if (i < total) {
+		const uint32_t slot = a.q_ray[(size_t)q * a.shard_cap + i];
+		const float4 r0 = a.ray0[slot], r1 = a.ray1[slot];
+		Ray ray = {mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y)};
+		HitRec h;
+		traverse_dyn<false, COUNT, true>(a.tree, ray, FLT_MAX, lds_stack + threadIdx.x, depth, h, wc);
+		a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
+	}
+	if (COUNT)
+		count_flush(a.cnt, wc);
+}
+
+// The rays that need the division-based box test.  Any grid that is a multiple
+// of kShards works: the workgroups of a shard stride over its sub-queue.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_intersect_odd(const RenderArgs a, const int par, const int depth)
+{
+	extern __shared__ uint32_t lds_stack[];
+	const uint32_t shard = blockIdx.x % kShards, part = blockIdx.x / kShards, parts = gridDim.x / kShards;
+	const uint32_t q = ray_queue_index(par, kOddRays, shard);
+	const uint32_t total = a.cnt->n_ray[q];
+	WorkCount wc = {0, 0, 0};
+	for (uint32_t i = part * kBlock + threadIdx.x; i < total; i += parts * kBlock) {
+		const uint32_t slot = a.q_ray[(size_t)q * a.shard_cap + i];
+		const float4 r0 = a.ray0[slot], r1 = a.ray1[slot];
+		Ray ray = {mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y)};
+		HitRec h;
+		traverse_dyn<false, COUNT, false>(a.tree, ray, FLT_MAX, lds_stack + threadIdx.x, depth, h, wc);
+		a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
+	}
+	if (COUNT)
+		count_flush(a.cnt, wc);
 }
 
 // ------------------------------------------------------------------ shadow
@@ -539,10 +551,6 @@ __global__ __launch_bounds__(kBlock) void k_init_slots(const RenderArgs a, uint3
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
 	if (i >= n_slots)
 		return;
-	a.acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-	a.col[i] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
-	a.thr[i] = make_float4(1.f, 1.f, 1.f, __uint_as_float(1u));
-	a.meta[i] = make_uint4(0u, 0u, 0u, 0u);
 	a.ray1[i] = make_float4(0.f, 0.f, 1.f, __uint_as_float(kWaiting));
 }
 
@@ -619,9 +627,9 @@ void launch_init_slots(hipStream_t s, const RenderArgs &a, uint32_t n_slots)
 	hipLaunchKernelGGL(k_init_slots, dim3(blocks_for(n_slots)), dim3(kBlock), 0, s, a, n_slots);
 }
 
-void launch_generate(hipStream_t s, const RenderArgs &a, int par)
+void launch_advance(hipStream_t s, const RenderArgs &a, int par)
 {
-	hipLaunchKernelGGL(k_generate, dim3(blocks_for(a.n_slots)), dim3(kBlock), 0, s, a, par);
+	hipLaunchKernelGGL(k_advance, dim3(blocks_for(a.n_slots)), dim3(kBlock), 0, s, a, par);
 }
 
 void launch_intersect(hipStream_t s, const RenderArgs &a, int par, int depth, bool count)
@@ -638,11 +646,6 @@ void launch_intersect(hipStream_t s, const RenderArgs &a, int par, int depth, bo
 	else
 		hipLaunchKernelGGL(k_intersect_odd<false>, dim3(odd_blocks), dim3(kBlock), stack_bytes(depth), s, a, par,
 		                   depth);
-}
-
-void launch_shade(hipStream_t s, const RenderArgs &a, int par)
-{
-	hipLaunchKernelGGL(k_shade, dim3(blocks_for(a.n_slots)), dim3(kBlock), 0, s, a, par);
 }
 
 void launch_shadow(hipStream_t s, const RenderArgs &a, uint32_t bound, int depth, bool count)

@@ -46,9 +46,10 @@ struct RenderArgs {
 	float4 *ray0;                  // origin xyz, direction x
 	float4 *ray1;                  // direction yz, pdf of the sampled direction, bounce or slot state
 	float4 *hit;                   // primitive, t, u, v
-	float4 *thr;                   // throughput rgb, rng state
-	float4 *col;                   // path radiance rgb, samples finished in the current block
-	float4 *acc;                   // block sum rgb
+	float4 *thr;                   // throughput rgb (kept from the second segment of a path on)
+	float4 *col;                   // path radiance rgb (likewise)
+	uint32_t *rng;                 // xorshift32 state of the slot's stream
+	float4 *acc;                   // block sum rgb, samples finished in the current block
 	uint4 *meta;                   // pixel, current block, end of the block run, index in the padded pixel list
 	uint32_t n_slots;
 	uint32_t *q_ray;               // closest-hit queues, [step parity][kind][shard][shard_cap] slot numbers
@@ -72,9 +73,8 @@ struct RenderArgs {
 };
 
 void launch_init_slots(hipStream_t s, const RenderArgs &a, uint32_t n_slots);
-void launch_generate(hipStream_t s, const RenderArgs &a, int par);
+void launch_advance(hipStream_t s, const RenderArgs &a, int par);
 void launch_intersect(hipStream_t s, const RenderArgs &a, int par, int depth, bool count);
-void launch_shade(hipStream_t s, const RenderArgs &a, int par);
 void launch_shadow(hipStream_t s, const RenderArgs &a, uint32_t bound, int depth, bool count);
 void launch_sum_blocks(hipStream_t s, const float4 *partial, const int32_t *pixels, uint32_t n_pad, uint32_t n_blocks,
                        float *frame);

@@ -468,7 +468,7 @@ int rta_debug_trace_variant(rta_context *ctx, int variant, const float *rays, in
 		return rta_trace_closest(ctx, rays, n, hits, mem);
 	if (!ctx->have_scene)
 		return ctx->fail(RTA_E_NO_SCENE, "no scene uploaded");
-	if (variant < 1 || variant > 4 || n <= 0 || !rays || !hits || mem != RTA_MEM_DEVICE)
+	if (variant < 1 || (variant > 4 && variant < 100) || variant > 360 || (variant >= 200 && variant - 200 < ctx->stack_depth) || n <= 0 || !rays || !hits || mem != RTA_MEM_DEVICE)
 		return ctx->fail(RTA_E_INVALID, "variants 1..4 take device-resident ray batches");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	launch_variant(ctx->stream, variant, tree_of(ctx), ctx->ref_nodes.as<const float4>(), rays, (uint64_t)n, hits,
@@ -596,7 +596,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 
 	// The slot pool: `groups` equal parts of whole workgroups, never more waves
 	// than there are (tile, block run) pairs to hand out.
-	uint64_t want_waves = ((p->slots > 0 ? (uint64_t)p->slots : (1u << 22)) + 63) / 64;
+	uint64_t want_waves = ((p->slots > 0 ? (uint64_t)p->slots : (1u << 24)) + 63) / 64;
 	want_waves = std::min<uint64_t>(want_waves, std::max<uint64_t>(items64, 1));
 	int groups = p->streams > 0 ? std::min(p->streams, kMaxGroups) : 4;
 	const uint64_t waves_per_block = 256 / 64;
@@ -669,6 +669,8 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	base.max_bounces = p->max_bounces > 0 ? p->max_bounces : 10;
 	memcpy(base.sky, p->sky, sizeof base.sky);
 	base.cam = *camera;
+	base.rays_per_lane = 4;       // measured on dragon.txt: 2 and 8 lose 2-4 %
+	base.refill_at = 16;          // likewise 8 and 32
 
 	// one RenderArgs and one stream per slot group
 	std::vector<RenderArgs> ga((size_t)groups, base);

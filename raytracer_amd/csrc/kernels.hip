@@ -401,34 +401,106 @@ RTA_DEV void step_housekeeping(const RenderArgs &a, int par)
 			atomicAdd(&a.cnt->rays, (unsigned long long)n);
 		a.cnt->n_ray[ray_queue_index(par ^ 1, 0, 0) + threadIdx.x] = 0;
 	}
+	if (threadIdx.x < kShards)
+		a.cnt->head[(uint32_t)(par ^ 1) * kShards + threadIdx.x] = 0;
 	if (threadIdx.x == 0)
 		a.cnt->n_shadow = 0;
 }
 
-// Camera and bounce rays.  Grid: 2 kinds x kShards sub-queues x
-// (shard_cap / kBlock) workgroups, shards innermost so that the first
-// workgroups of all shards start together; a workgroup whose part of its
-// sub-queue is empty leaves at once.
+// Bounce rays differ widely in length (on the dragon: 41 node visits and
+// primitive tests on average, 95 at the 99th percentile), so a wave that took 64
+// of them and ran until the last was through would keep 43 % of its lanes busy.
+// Instead few waves each work through rays_per_lane x 64 rays: whenever
+// refill_at lanes have run out of work the wave stores their hits and draws as
+// many new rays from its sub-queue (one atomic per refill), until the sub-queue
+// is dry.
+
+RTA_DEV uint32_t pulling_blocks(uint32_t n_rays, uint32_t rpl) { return (n_rays + kBlock * rpl - 1) / (kBlock * rpl); }
+
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_intersect(const RenderArgs a, const int par, const int depth)
+RTA_DEV void intersect_pulling(const RenderArgs &a, const uint32_t q, const uint32_t total, uint32_t *head,
+                               uint32_t *stack, const int depth, WorkCount &wc)
+{
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t *queue = a.q_ray + (size_t)q * a.shard_cap;
+	Traversal<false, COUNT, true> tr;
+	tr.rest();
+	uint32_t slot = 0;
+	bool loaded = false, dry = false;
+	for (;;) {
+		const unsigned long long idle = __ballot(!tr.more);
+		const uint32_t n_idle = (uint32_t)__popcll(idle);
+		if (!dry && n_idle >= a.refill_at) {
+			if (!tr.more && loaded) {
+				const HitRec h = tr.result();
+				a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
+				loaded = false;
+			}
+			uint32_t base = 0;
+			if (lane == 0)
+				base = atomicAdd(head, n_idle);
+			base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+			const uint32_t got = base < total ? (total - base < n_idle ? total - base : n_idle) : 0u;
+			dry = got < n_idle;
+			const uint32_t rank =
+			    __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+			if (!tr.more && rank < got) {
+				slot = queue[base + rank];
+				const float4 r0 = a.ray0[slot], r1 = a.ray1[slot];
+				tr.start(a.tree, Ray{mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y)}, FLT_MAX);
+				loaded = true;
+			}
+		}
+		if (__ballot(tr.more) == 0) {
+			if (dry)
+				break;
+			continue;        // every lane idle and the queue not known to be dry: the next trip refills
+		}
+		if (tr.more)
+			tr.step(a.tree, stack, depth, wc);
+	}
+	if (loaded) {
+		const HitRec h = tr.result();
+		a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
+	}
+}
+
+// Camera and bounce rays.  Grid: first the workgroups that pull bounce rays
+// (kShards sub-queues x the most a sub-queue can need), then one workgroup per
+// kBlock camera-ray entries (kShards x shard_cap / kBlock); shards innermost so
+// that the first workgroups of all shards start together.  A workgroup with
+// nothing to do leaves at once.
+RTA_DEV uint32_t pulling_grid(uint32_t shard_cap, uint32_t rpl) { return kShards * pulling_blocks(shard_cap, rpl); }
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_intersect(const RenderArgs a, const int par, const int depth)
 {
 	extern __shared__ uint32_t lds_stack[];
-	const uint32_t per_kind = kShards * (a.shard_cap / kBlock);
-	const uint32_t kind = blockIdx.x / per_kind, rem = blockIdx.x - kind * per_kind;
-	const uint32_t shard = rem % kShards, part = rem / kShards;
-	const uint32_t q = ray_queue_index(par, (int)kind, shard);
-	const uint32_t total = a.cnt->n_ray[q];
 	if (blockIdx.x == 0)
 		step_housekeeping(a, par);
-	const uint32_t i = part * kBlock + threadIdx.x;
 	WorkCount wc = {0, 0, 0};
-	if (i < total) {
-		const uint32_t slot = a.q_ray[(size_t)q * a.shard_cap + i];
-		const float4 r0 = a.ray0[slot], r1 = a.ray1[slot];
-		Ray ray = {mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y)};
-		HitRec h;
-		traverse_dyn<false, COUNT, true>(a.tree, ray, FLT_MAX, lds_stack + threadIdx.x, depth, h, wc);
-		a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
+	const uint32_t n_pulling = pulling_grid(a.shard_cap, a.rays_per_lane);
+	if (blockIdx.x < n_pulling) {
+		const uint32_t shard = blockIdx.x % kShards, part = blockIdx.x / kShards;
+		const uint32_t q = ray_queue_index(par, kBounceRays, shard);
+		const uint32_t total = a.cnt->n_ray[q];
+		if (part < pulling_blocks(total, a.rays_per_lane))
+			intersect_pulling<COUNT>(a, q, total, &a.cnt->head[(uint32_t)par * kShards + shard],
+			                         lds_stack + threadIdx.x, depth, wc);
+	} else {
+		const uint32_t rem = blockIdx.x - n_pulling;
+		const uint32_t shard = rem % kShards, part = rem / kShards;
+		const uint32_t q = ray_queue_index(par, kCameraRays, shard);
+		const uint32_t total = a.cnt->n_ray[q];
+		const uint32_t i = part * kBlock + threadIdx.x;
+		if (i < total) {
+			const uint32_t slot = a.q_ray[(size_t)q * a.shard_cap + i];
+			const float4 r0 = a.ray0[slot], r1 = a.ray1[slot];
+			Ray ray = {mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y)};
+			HitRec h;
+			traverse_dyn<false, COUNT, true>(a.tree, ray, FLT_MAX, lds_stack + threadIdx.x, depth, h, wc);
+			a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
+		}
 	}
 	if (COUNT)
 		count_flush(a.cnt, wc);
@@ -459,7 +531,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect_odd(const RenderArgs a, co
 // ------------------------------------------------------------------ shadow
 
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_shadow(const RenderArgs a, const int depth)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_shadow(const RenderArgs a, const int depth)
 {
 	extern __shared__ uint32_t lds_stack[];
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -634,7 +706,7 @@ void launch_advance(hipStream_t s, const RenderArgs &a, int par)
 
 void launch_intersect(hipStream_t s, const RenderArgs &a, int par, int depth, bool count)
 {
-	const unsigned blocks = 2 * kShards * (a.shard_cap / kBlock);
+	const unsigned blocks = kShards * ((a.shard_cap / kBlock + a.rays_per_lane - 1) / a.rays_per_lane) + kShards * (a.shard_cap / kBlock);
 	if (count)
 		hipLaunchKernelGGL(k_intersect<true>, dim3(blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);
 	else

@@ -174,6 +174,31 @@ RTA_DEV float test_box_tame(V3 lo, V3 hi, const Ray &r, V3 rcp, float max_t)
 	return (tmax >= tmin && tmin < max_t && tmax > 0) ? tmin : FLT_MAX;
 }
 
+// Entry and exit distance of a box from plain products with the reciprocal.
+// Each product t' = RN(RN(plane - o) * RN(1/d)) is within a factor 1 +- 3*2^-24
+// of the reference's quotient t = RN(RN(plane - o) / d) and has the same sign
+// (tame rays and scenes: nothing under- or overflows), and min/max are
+// monotonic, so the box's true entry distance lies within the same factor of
+// t_in and, where t_out > 0, the true exit distance within it of t_out; t_in = 0
+// means the true entry distance is 0, t_out <= 0 that the true one is <= 0.
+// The traversal only ever COMPARES these distances (hit or miss, which child is
+// nearer), so it decides from the approximations whenever they are further apart
+// than the error and computes the quotients only for the rare close calls.
+RTA_DEV void approx_box(V3 lo, V3 hi, const Ray &r, V3 rcp, float &t_in, float &t_out)
+{
+	const float ax = (lo.x - r.o.x) * rcp.x, bx = (hi.x - r.o.x) * rcp.x;
+	const float ay = (lo.y - r.o.y) * rcp.y, by = (hi.y - r.o.y) * rcp.y;
+	const float az = (lo.z - r.o.z) * rcp.z, bz = (hi.z - r.o.z) * rcp.z;
+	const float ix = __builtin_fminf(ax, bx), iy = __builtin_fminf(ay, by), iz = __builtin_fminf(az, bz);
+	const float ox = __builtin_fmaxf(ax, bx), oy = __builtin_fmaxf(ay, by), oz = __builtin_fmaxf(az, bz);
+	t_in = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(ix, iy), iz), 0.f);
+	t_out = __builtin_fminf(__builtin_fminf(ox, oy), oz);
+}
+
+// a > b * kApart (or a * kApart < b) proves a > b for the true distances:
+// 1 + 2^-19 covers (1 + 3*2^-24) / (1 - 3*2^-24) and the rounding of the product
+constexpr float kApart = 1.f + 0x1p-19f;
+
 // Traversal of src/main.cpp:332-422 (closest, ANY = false) and :424-478 (any
 // hit, ANY = true), kept as an explicit per-lane state machine: step() does one
 // unit of work, either one inner-node visit (both child boxes) or one primitive
@@ -213,11 +238,37 @@ struct Traversal {
 		more = true;
 	}
 
+	// A lane without a ray: more is false and result() says "no hit".
+	RTA_DEV void rest()
+	{
+		ray = Ray{mk(0, 0, 0), mk(1, 1, 1)};
+		rcp = mk(1, 1, 1);
+		sg = RaySigns{false, false, false};
+		tame = true;
+		best = FLT_MAX;
+		prim = -1;
+		u = v = 0.f;
+		node = 0;
+		sp = 0;
+		more = false;
+	}
+
+	RTA_DEV bool at_prim() const { return (node & kLeafBit) != 0; }
+
 	// One unit of work: either one inner-node visit or one primitive test.
 	// Precondition: more.
 	RTA_DEV void step(const DeviceTree &tree, uint32_t *stack, const int depth, WorkCount &work)
 	{
-		if (node & kLeafBit) {
+		if (at_prim())
+			test_prim(tree, stack, work);
+		else
+			visit_inner(tree, stack, depth, work);
+	}
+
+	// Precondition: more && at_prim()
+	RTA_DEV void test_prim(const DeviceTree &tree, uint32_t *stack, WorkCount &work)
+	{
+		{
 			const uint32_t i = node & ~kLeafBit;
 			const float4 p0 = tree.prims[3 * (size_t)i];
 			const float4 p1 = tree.prims[3 * (size_t)i + 1];
@@ -247,36 +298,61 @@ struct Traversal {
 				node = stack[(--sp) * STRIDE];
 			else
 				more = false;
-		} else {
+		}
+	}
+
+	// Precondition: more && !at_prim()
+	RTA_DEV void visit_inner(const DeviceTree &tree, uint32_t *stack, const int depth, WorkCount &work)
+	{
+		{
 			if (COUNT) work.inner++;
 			const float4 *rec = tree.pairs + 4 * (size_t)node;
 			const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
 			const uint32_t ref1 = __float_as_uint(q3.x), ref2 = __float_as_uint(q3.y);
-			float d1, d2;
-			if (TAME_ONLY || tame) {
-				d1 = test_box_tame(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), ray, rcp, best);
-				d2 = test_box_tame(mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w), ray, rcp, best);
-			} else {
-				d1 = test_box(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), ray, sg, best);
-				d2 = test_box(mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w), ray, sg, best);
+			const V3 lo1 = mk(q0.x, q0.y, q0.z), hi1 = mk(q0.w, q1.x, q1.y);
+			const V3 lo2 = mk(q1.z, q1.w, q2.x), hi2 = mk(q2.y, q2.z, q2.w);
+			bool hit1, hit2, one_near;      // one_near: the first child is visited first
+			bool exact = !(TAME_ONLY || tame);
+			if (!exact) {
+				float i1, o1, i2, o2;
+				approx_box(lo1, hi1, ray, rcp, i1, o1);
+				approx_box(lo2, hi2, ray, rcp, i2, o2);
+				const float far = best * kApart;      // may be +inf
+				const float i1k = i1 * kApart, o1k = o1 * kApart, i2k = i2 * kApart, o2k = o2 * kApart;
+				// the three conditions of the reference's box test (src/main.cpp:329),
+				// each either proven false (miss) or all proven true (hit)
+				const bool miss1 = o1 <= 0.f || o1k < i1 || i1 >= far;
+				const bool miss2 = o2 <= 0.f || o2k < i2 || i2 >= far;
+				hit1 = o1 > 0.f && o1 >= i1k && i1k < best;
+				hit2 = o2 > 0.f && o2 >= i2k && i2k < best;
+				exact = (!miss1 && !hit1) || (!miss2 && !hit2);
+				if (ANY) {
+					one_near = true;
+				} else {
+					// src/main.cpp:391-401 compares the boxes' distances, FLT_MAX for a miss
+					const bool nearer = i1k < i2, not_nearer = i1 >= i2k;
+					one_near = hit1 && (!hit2 || nearer);
+					exact = exact || (hit1 && hit2 && !nearer && !not_nearer);
+				}
 			}
-			uint32_t first, second;
-			bool hit_first, hit_second;
-			if (ANY) {
-				// first child first, no ordering (src/main.cpp:460-473)
-				first = ref1;
-				second = ref2;
-				hit_first = d1 < FLT_MAX;
-				hit_second = d2 < FLT_MAX;
-			} else {
-				// nearer child first; on equal distances the SECOND child is "near"
-				// (src/main.cpp:391-401)
-				const bool one_near = d1 < d2;
-				first = one_near ? ref1 : ref2;
-				second = one_near ? ref2 : ref1;
-				hit_first = (one_near ? d1 : d2) < FLT_MAX;
-				hit_second = (one_near ? d2 : d1) < FLT_MAX;
+			if (exact) {
+				float d1, d2;
+				if (TAME_ONLY || tame) {
+					d1 = test_box_tame(lo1, hi1, ray, rcp, best);
+					d2 = test_box_tame(lo2, hi2, ray, rcp, best);
+				} else {
+					d1 = test_box(lo1, hi1, ray, sg, best);
+					d2 = test_box(lo2, hi2, ray, sg, best);
+				}
+				hit1 = d1 < FLT_MAX;
+				hit2 = d2 < FLT_MAX;
+				one_near = ANY || d1 < d2;
 			}
+			// closest hit: nearer child first, and on equal distances the SECOND
+			// child is "near" (src/main.cpp:391-401); any hit: first child first,
+			// no ordering (src/main.cpp:460-473)
+			const uint32_t first = one_near ? ref1 : ref2, second = one_near ? ref2 : ref1;
+			const bool hit_first = one_near ? hit1 : hit2, hit_second = one_near ? hit2 : hit1;
 			if (hit_first) {
 				node = first;
 				if (hit_second && sp < depth) {      // sp == depth cannot happen on a validated tree

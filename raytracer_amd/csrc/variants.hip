@@ -210,6 +210,45 @@ __global__ __launch_bounds__(kBlock) void k_variant_nested_loops(const DeviceTre
 	hits[i] = rta_hit{prim, best, bu, bv};
 }
 
+// Experiment: a trip runs a branch only if at least `threshold` lanes want it
+// or it is the majority's; the minority's lanes wait for company.
+__global__ __launch_bounds__(kBlock) void k_variant_threshold(const DeviceTree tree, const float *rays, uint64_t n,
+                                                              rta_hit *hits, const int depth, const int threshold)
+{
+	extern __shared__ uint32_t lds_stack[];
+	uint32_t *stack = lds_stack + threadIdx.x;
+	const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+	if (i >= n)
+		return;
+	const float *r = rays + i * 6;
+	Traversal<false, false> tr;
+	WorkCount wc = {0, 0, 0};
+	tr.start(tree, Ray{mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5])}, FLT_MAX);
+	uint32_t trips = 0, units = 0, both = 0;
+	for (;;) {
+		const bool want_prim = tr.more && tr.at_prim(), want_inner = tr.more && !tr.at_prim();
+		const int n_prim = __popcll(__ballot(want_prim)), n_inner = __popcll(__ballot(want_inner));
+		if (n_prim + n_inner == 0)
+			break;
+		trips++;
+		units += tr.more;
+		both += n_prim > 0 && n_inner > 0;
+		if (n_inner >= threshold || n_inner >= n_prim) {
+			if (want_inner)
+				tr.visit_inner(tree, stack, depth, wc);
+		}
+		if (n_prim >= threshold || n_prim > n_inner) {
+			if (want_prim)
+				tr.test_prim(tree, stack, wc);
+		}
+	}
+	const HitRec h = tr.result();
+	if (threshold == 0)      // statistics instead of the hit: trips of the wave, units of the lane, trips with both branches
+		hits[i] = rta_hit{(int32_t)trips, (float)units, (float)both, 0.f};
+	else
+		hits[i] = rta_hit{h.prim, h.t, h.u, h.v};
+}
+
 }  // namespace
 
 void launch_variant(hipStream_t s, int variant, const TreeRef &tree, const float4 *reference_nodes, const float *rays,
@@ -217,6 +256,17 @@ void launch_variant(hipStream_t s, int variant, const TreeRef &tree, const float
 {
 	const unsigned blocks = (unsigned)((n + kBlock - 1) / kBlock);
 	const size_t lds = (size_t)depth * kBlock * sizeof(uint32_t);
+	if (variant >= 200) {
+		// occupancy experiment: LDS sized for (variant - 200) stack entries
+		hipLaunchKernelGGL(k_variant_threshold, dim3(blocks), dim3(kBlock), (size_t)(variant - 200) * kBlock * 4, s, tree,
+		                   rays, n, hits, depth, 1);
+		return;
+	}
+	if (variant >= 100) {
+		hipLaunchKernelGGL(k_variant_threshold, dim3(blocks), dim3(kBlock), lds, s, tree, rays, n, hits, depth,
+		                   variant - 100);
+		return;
+	}
 	switch (variant) {
 	case 1:
 		hipLaunchKernelGGL(k_variant_private_stack, dim3(blocks), dim3(kBlock), 0, s, tree, rays, n, hits);

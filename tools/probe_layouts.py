@@ -49,19 +49,32 @@ def main():
         rt = torch.from_numpy(np.ascontiguousarray(rr)).to(dev)
         n = rr.shape[0]
         base = None
-        for variant in (0, 1, 2, 3, 4):
+        for variant in [int(v) for v in os.environ.get("VARIANTS", "0,1,2,3,4").split(",")]:
             ht = torch.zeros((n, 4), dtype=torch.float32, device=dev)
-            ctx.trace_variant_device(variant, rt.data_ptr(), n, ht.data_ptr())
+            try:
+                ctx.trace_variant_device(variant, rt.data_ptr(), n, ht.data_ptr())
+            except rta.RtaError as e:
+                print(f"{label:20s} variant {variant} refused: {e}", flush=True)
+                continue
             best = 1e9
             for _ in range(reps):
                 t0 = time.perf_counter()
                 ctx.trace_variant_device(variant, rt.data_ptr(), n, ht.data_ptr())
                 best = min(best, time.perf_counter() - t0)
             res = ht.cpu().numpy().view(np.uint32)
+            if variant == 100:
+                f = ht.cpu().numpy()
+                trips = f[:, 0].view(np.int32).astype(np.float64)
+                if os.environ.get("SAVE_UNITS"):
+                    np.save(os.path.join(ROOT, "gpurun_out", "units_" + label.split()[0] + ".npy"),
+                            f[:len(f) // (8 if label.startswith("bounce") else 1), 1].astype(np.uint16))
+                print(f"{label:20s} trips per wave {trips[::64].mean():.1f} (max {trips.max():.0f}), units per ray {f[:, 1].mean():.1f}, "
+                      f"trips with both branches {f[::64, 2].mean():.1f}, lane occupancy {f[:, 1].sum() / trips.sum():.3f}", flush=True)
+                continue
             if base is None:
                 base = res
             same = np.array_equal(res, base)
-            print(f"{label:20s} variant {variant} {NAMES[variant]:62s} {best * 1e3:8.3f} ms {n / best / 1e9:6.2f} Grays/s"
+            print(f"{label:20s} variant {variant} {NAMES.get(variant, 'experiment'):62s} {best * 1e3:8.3f} ms {n / best / 1e9:6.2f} Grays/s"
                   f"  same_bits={same}", flush=True)
             assert same
 

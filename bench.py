@@ -36,11 +36,11 @@ import raytracer_amd as rta  # noqa: E402
 # with the reference traversal's own visit counts per workload.
 WORKLOADS = {
     "dragon1080p": dict(scene="dragon.txt", width=1920, height=1080, spp=1024, bytes_per_ray=691.0,
-                        cpu_spp=32, label="scenes/dragon.txt 1920x1080 1024spp"),
+                        cpu_spp=256, label="scenes/dragon.txt 1920x1080 1024spp"),
     "cornell1080p": dict(scene="cornell_box.txt", width=1920, height=1080, spp=256, bytes_per_ray=764.0,
-                         cpu_spp=16, label="scenes/cornell_box.txt 1920x1080 256spp"),
+                         cpu_spp=64, label="scenes/cornell_box.txt 1920x1080 256spp"),
     "dragon4k": dict(scene="dragon.txt", width=3840, height=2160, spp=4096, bytes_per_ray=691.0,
-                     cpu_spp=8, label="scenes/dragon.txt 3840x2160 4096spp"),
+                     cpu_spp=64, label="scenes/dragon.txt 3840x2160 4096spp"),
 }
 HBM_PEAK_GBS = 8000.0
 
@@ -202,6 +202,7 @@ def main():
                          "kernel": "k_intersect", "avg_launch_ms": avg_ms, "launches": launches,
                          "rays_per_launch": rays_per_launch, "bytes_per_ray": w["bytes_per_ray"],
                          "concurrent_streams": args.streams or 4,
+                         "pipeline_frac": rays_all / elapsed * w["bytes_per_ray"] / 1e9 / HBM_PEAK_GBS / world,
                          "intersect_launch_time_over_gpu_time": tot["intersect_ms"] / max(tot["gpu_ms"], 1e-9)},
         }
         # HBM bytes per intersect launch from the committed PMC profile of this workload

@@ -256,22 +256,41 @@ struct Traversal {
 	RTA_DEV bool at_prim() const { return (node & kLeafBit) != 0; }
 
 	// One unit of work: either one inner-node visit or one primitive test.
-	// Precondition: more.
+	// Precondition: more.  The record's first 48 bytes are loaded by the same three
+	// instructions whichever kind the lane's node is: a load instruction occupies
+	// the memory pipeline for the whole wave however few lanes take part, so a trip
+	// in which some lanes visit nodes and others test primitives issues four loads
+	// instead of seven.
 	RTA_DEV void step(const DeviceTree &tree, uint32_t *stack, const int depth, WorkCount &work)
 	{
-		if (at_prim())
-			test_prim(tree, stack, work);
+		const bool leaf = at_prim();
+		const float4 *rec = leaf ? tree.prims + 3 * (size_t)(node & ~kLeafBit) : tree.pairs + 4 * (size_t)node;
+		const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+		if (leaf)
+			prim_unit(q0, q1, q2, stack, work);
 		else
-			visit_inner(tree, stack, depth, work);
+			inner_unit(q0, q1, q2, rec[3], stack, depth, work);
 	}
 
 	// Precondition: more && at_prim()
 	RTA_DEV void test_prim(const DeviceTree &tree, uint32_t *stack, WorkCount &work)
 	{
+		const float4 *rec = tree.prims + 3 * (size_t)(node & ~kLeafBit);
+		prim_unit(rec[0], rec[1], rec[2], stack, work);
+	}
+
+	// Precondition: more && !at_prim()
+	RTA_DEV void visit_inner(const DeviceTree &tree, uint32_t *stack, const int depth, WorkCount &work)
+	{
+		const float4 *rec = tree.pairs + 4 * (size_t)node;
+		inner_unit(rec[0], rec[1], rec[2], rec[3], stack, depth, work);
+	}
+
+	// p0..p2: the primitive's record
+	RTA_DEV void prim_unit(const float4 p0, const float4 p1, const float4 p2, uint32_t *stack, WorkCount &work)
+	{
 		{
 			const uint32_t i = node & ~kLeafBit;
-			const float4 p0 = tree.prims[3 * (size_t)i];
-			const float4 p1 = tree.prims[3 * (size_t)i + 1];
 			const uint32_t flags = __float_as_uint(p0.w);
 			float t, tu = 0, tv = 0;
 			if (flags & kPrimSphere) {
@@ -279,7 +298,6 @@ struct Traversal {
 				t = test_sphere(mk(p0.x, p0.y, p0.z), p1.x, ray);
 			} else {
 				if (COUNT) work.tri++;
-				const float4 p2 = tree.prims[3 * (size_t)i + 2];
 				t = test_triangle(mk(p0.x, p0.y, p0.z), mk(p1.x, p1.y, p1.z), mk(p2.x, p2.y, p2.z), ray, tu, tv);
 			}
 			if (t < best) {           // strict: the first-visited primitive keeps a tie
@@ -301,13 +319,12 @@ struct Traversal {
 		}
 	}
 
-	// Precondition: more && !at_prim()
-	RTA_DEV void visit_inner(const DeviceTree &tree, uint32_t *stack, const int depth, WorkCount &work)
+	// q0..q3: the pair record of the node
+	RTA_DEV void inner_unit(const float4 q0, const float4 q1, const float4 q2, const float4 q3, uint32_t *stack,
+	                        const int depth, WorkCount &work)
 	{
 		{
 			if (COUNT) work.inner++;
-			const float4 *rec = tree.pairs + 4 * (size_t)node;
-			const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
 			const uint32_t ref1 = __float_as_uint(q3.x), ref2 = __float_as_uint(q3.y);
 			const V3 lo1 = mk(q0.x, q0.y, q0.z), hi1 = mk(q0.w, q1.x, q1.y);
 			const V3 lo2 = mk(q1.z, q1.w, q2.x), hi2 = mk(q2.y, q2.z, q2.w);

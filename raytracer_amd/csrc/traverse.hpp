@@ -266,6 +266,9 @@ struct Traversal {
 		const bool leaf = at_prim();
 		const float4 *rec = leaf ? tree.prims + 3 * (size_t)(node & ~kLeafBit) : tree.pairs + 4 * (size_t)node;
 		const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+		// keep the three loads whole (a primitive does not use q1.w and q2.w; loading
+		// them apart for nodes would cost a fifth instruction)
+		asm volatile("" ::"v"(q1.w), "v"(q2.w));
 		if (leaf)
 			prim_unit(q0, q1, q2, stack, work);
 		else

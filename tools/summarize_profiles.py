@@ -17,7 +17,7 @@ import os
 import shutil
 import sys
 
-KERNELS = ("k_intersect_odd", "k_intersect", "k_shade", "k_generate", "k_shadow", "k_sum_blocks", "k_resolve")
+KERNELS = ("k_intersect_odd", "k_intersect", "k_advance", "k_shadow", "k_sum_blocks", "k_resolve")
 
 
 def kernel_of(name):

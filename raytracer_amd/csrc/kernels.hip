@@ -403,67 +403,16 @@ RTA_DEV void step_housekeeping(const RenderArgs &a, int par)
 	}
 	if (threadIdx.x < kShards)
 		a.cnt->head[(uint32_t)(par ^ 1) * kShards + threadIdx.x] = 0;
+
 	if (threadIdx.x == 0)
 		a.cnt->n_shadow = 0;
 }
 
-// Bounce rays differ widely in length (on the dragon: 41 node visits and
-// primitive tests on average, 95 at the 99th percentile), so a wave that took 64
-// of them and ran until the last was through would keep 43 % of its lanes busy.
-// Instead few waves each work through rays_per_lane x 64 rays: whenever
-// refill_at lanes have run out of work the wave stores their hits and draws as
-// many new rays from its sub-queue (one atomic per refill), until the sub-queue
-// is dry.
-
+// Bounce rays are traced by few waves per sub-queue (one per rays_per_lane x 64
+// entries) that draw their rays from it as their lanes run out of work
+// (traverse_pulling); the waves of a sub-queue share its `head` counter, so a wave
+// that drew long rays simply draws fewer.
 RTA_DEV uint32_t pulling_blocks(uint32_t n_rays, uint32_t rpl) { return (n_rays + kBlock * rpl - 1) / (kBlock * rpl); }
-
-template <bool COUNT>
-RTA_DEV void intersect_pulling(const RenderArgs &a, const uint32_t q, const uint32_t total, uint32_t *head,
-                               uint32_t *stack, const int depth, WorkCount &wc)
-{
-	const uint32_t lane = threadIdx.x & 63;
-	const uint32_t *queue = a.q_ray + (size_t)q * a.shard_cap;
-	Traversal<false, COUNT, true> tr;
-	tr.rest();
-	uint32_t slot = 0;
-	bool loaded = false, dry = false;
-	for (;;) {
-		const unsigned long long idle = __ballot(!tr.more);
-		const uint32_t n_idle = (uint32_t)__popcll(idle);
-		if (!dry && n_idle >= a.refill_at) {
-			if (!tr.more && loaded) {
-				const HitRec h = tr.result();
-				a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
-				loaded = false;
-			}
-			uint32_t base = 0;
-			if (lane == 0)
-				base = atomicAdd(head, n_idle);
-			base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-			const uint32_t got = base < total ? (total - base < n_idle ? total - base : n_idle) : 0u;
-			dry = got < n_idle;
-			const uint32_t rank =
-			    __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-			if (!tr.more && rank < got) {
-				slot = queue[base + rank];
-				const float4 r0 = a.ray0[slot], r1 = a.ray1[slot];
-				tr.start(a.tree, Ray{mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y)}, FLT_MAX);
-				loaded = true;
-			}
-		}
-		if (__ballot(tr.more) == 0) {
-			if (dry)
-				break;
-			continue;        // every lane idle and the queue not known to be dry: the next trip refills
-		}
-		if (tr.more)
-			tr.step(a.tree, stack, depth, wc);
-	}
-	if (loaded) {
-		const HitRec h = tr.result();
-		a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
-	}
-}
 
 // Camera and bounce rays.  Grid: first the workgroups that pull bounce rays
 // (kShards sub-queues x the most a sub-queue can need), then one workgroup per
@@ -484,9 +433,22 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 		const uint32_t shard = blockIdx.x % kShards, part = blockIdx.x / kShards;
 		const uint32_t q = ray_queue_index(par, kBounceRays, shard);
 		const uint32_t total = a.cnt->n_ray[q];
-		if (part < pulling_blocks(total, a.rays_per_lane))
-			intersect_pulling<COUNT>(a, q, total, &a.cnt->head[(uint32_t)par * kShards + shard],
-			                         lds_stack + threadIdx.x, depth, wc);
+		if (part < pulling_blocks(total, a.rays_per_lane)) {
+			const uint32_t *queue = a.q_ray + (size_t)q * a.shard_cap;
+			traverse_pulling<false, COUNT, true>(
+			    a.tree, a.refill_at, lds_stack + threadIdx.x, depth, wc,
+			    SharedList{total, &a.cnt->head[(uint32_t)par * kShards + shard]},
+			    [&](uint32_t i, Ray &ray, float &limit) {
+				    const uint32_t slot = queue[i];
+				    const float4 r0 = a.ray0[slot], r1 = a.ray1[slot];
+				    ray = Ray{mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y)};
+				    limit = FLT_MAX;
+				    return slot;
+			    },
+			    [&](uint32_t slot, const HitRec &h) {
+				    a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
+			    });
+		}
 	} else {
 		const uint32_t rem = blockIdx.x - n_pulling;
 		const uint32_t shard = rem % kShards, part = rem / kShards;
@@ -628,42 +590,61 @@ __global__ __launch_bounds__(kBlock) void k_init_slots(const RenderArgs a, uint3
 
 // ------------------------------------------------------------------ ray batches
 
+// Ray batches: a wave owns a run of rays_per_lane x 64 consecutive rays (see
+// traverse_pulling); small batches get one ray per lane so that they still
+// spread over the whole GPU.
+constexpr uint32_t kBatchRefillAt = 16;
+
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_batch_closest(const DeviceTree tree, const float *rays, uint64_t n,
-                                                          rta_hit *hits, const int depth, Counters *cnt)
+                                                          rta_hit *hits, const int depth, Counters *cnt,
+                                                          const uint32_t rays_per_lane)
 {
 	extern __shared__ uint32_t lds_stack[];
-	const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+	// wave w of the grid owns rays [w 64 kBatchRaysPerLane, (w + 1) 64 kBatchRaysPerLane)
+	const uint64_t per_wave = 64 * (uint64_t)rays_per_lane;
+	const uint64_t begin = ((uint64_t)blockIdx.x * (kBlock / 64) + threadIdx.x / 64) * per_wave;
 	WorkCount wc = {0, 0, 0};
-	if (i < n) {
-		const float *r = rays + i * 6;
-		Ray ray = {mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5])};
-		HitRec h;
-		traverse_dyn<false, COUNT>(tree, ray, FLT_MAX, lds_stack + threadIdx.x, depth, h, wc);
-		rta_hit out;
-		out.prim = h.prim;
-		out.t = h.t;
-		out.u = h.u;
-		out.v = h.v;
-		hits[i] = out;
+	if (begin < n) {
+		const float *mine = rays + begin * 6;
+		rta_hit *out = hits + begin;
+		traverse_pulling<false, COUNT, false>(
+		    tree, kBatchRefillAt, lds_stack + threadIdx.x, depth, wc,
+		    OwnChunk{(uint32_t)(n - begin < per_wave ? n - begin : per_wave), 0u},
+		    [&](uint32_t i, Ray &ray, float &limit) {
+			    const float *r = mine + (size_t)i * 6;
+			    ray = Ray{mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5])};
+			    limit = FLT_MAX;
+			    return i;
+		    },
+		    [&](uint32_t i, const HitRec &h) { out[i] = rta_hit{h.prim, h.t, h.u, h.v}; });
 	}
 	if (COUNT)
 		count_flush(cnt, wc);
 }
 
 __global__ __launch_bounds__(kBlock) void k_batch_occluded(const DeviceTree tree, const float *rays, const float *tmax,
-                                                           uint64_t n, uint8_t *out, const int depth)
+                                                           uint64_t n, uint8_t *out, const int depth,
+                                                           const uint32_t rays_per_lane)
 {
 	extern __shared__ uint32_t lds_stack[];
-	const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-	if (i >= n)
+	const uint64_t per_wave = 64 * (uint64_t)rays_per_lane;
+	const uint64_t begin = ((uint64_t)blockIdx.x * (kBlock / 64) + threadIdx.x / 64) * per_wave;
+	if (begin >= n)
 		return;
-	const float *r = rays + i * 6;
-	Ray ray = {mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5])};
-	HitRec h;
+	const float *mine = rays + begin * 6, *limits = tmax + begin;
+	uint8_t *flags = out + begin;
 	WorkCount wc = {0, 0, 0};
-	traverse_dyn<true, false>(tree, ray, tmax[i], lds_stack + threadIdx.x, depth, h, wc);
-	out[i] = h.prim >= 0 ? 1 : 0;
+	traverse_pulling<true, false, false>(
+	    tree, kBatchRefillAt, lds_stack + threadIdx.x, depth, wc,
+	    OwnChunk{(uint32_t)(n - begin < per_wave ? n - begin : per_wave), 0u},
+	    [&](uint32_t i, Ray &ray, float &limit) {
+		    const float *r = mine + (size_t)i * 6;
+		    ray = Ray{mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5])};
+		    limit = limits[i];
+		    return i;
+	    },
+	    [&](uint32_t i, const HitRec &h) { flags[i] = h.prim >= 0 ? 1 : 0; });
 }
 
 __global__ __launch_bounds__(kBlock) void k_arith(int op, const float *x, const float *y, float *out, uint64_t n)
@@ -692,6 +673,8 @@ __global__ __launch_bounds__(kBlock) void k_arith(int op, const float *x, const 
 // ------------------------------------------------------------------ launchers
 
 static inline unsigned blocks_for(uint64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+static inline uint32_t batch_rays_per_lane(uint64_t n) { return n >= (8u << 20) ? 4u : 1u; }
+static inline unsigned batch_blocks(uint64_t n) { return blocks_for((n + batch_rays_per_lane(n) - 1) / batch_rays_per_lane(n)); }
 static inline size_t stack_bytes(int depth) { return (size_t)depth * kBlock * sizeof(uint32_t); }
 
 void launch_init_slots(hipStream_t s, const RenderArgs &a, uint32_t n_slots)
@@ -745,18 +728,18 @@ void launch_batch_closest(hipStream_t s, const TreeRef &tree, const float *rays,
                           Counters *cnt)
 {
 	if (cnt)
-		hipLaunchKernelGGL(k_batch_closest<true>, dim3(blocks_for(n)), dim3(kBlock), stack_bytes(depth), s, tree, rays,
-		                   n, hits, depth, cnt);
+		hipLaunchKernelGGL(k_batch_closest<true>, dim3(batch_blocks(n)), dim3(kBlock), stack_bytes(depth), s, tree, rays,
+		                   n, hits, depth, cnt, batch_rays_per_lane(n));
 	else
-		hipLaunchKernelGGL(k_batch_closest<false>, dim3(blocks_for(n)), dim3(kBlock), stack_bytes(depth), s, tree, rays,
-		                   n, hits, depth, cnt);
+		hipLaunchKernelGGL(k_batch_closest<false>, dim3(batch_blocks(n)), dim3(kBlock), stack_bytes(depth), s, tree,
+		                   rays, n, hits, depth, cnt, batch_rays_per_lane(n));
 }
 
 void launch_batch_occluded(hipStream_t s, const TreeRef &tree, const float *rays, const float *tmax, uint64_t n,
                            uint8_t *out, int depth)
 {
-	hipLaunchKernelGGL(k_batch_occluded, dim3(blocks_for(n)), dim3(kBlock), stack_bytes(depth), s, tree, rays, tmax, n,
-	                   out, depth);
+	hipLaunchKernelGGL(k_batch_occluded, dim3(batch_blocks(n)), dim3(kBlock), stack_bytes(depth), s, tree, rays, tmax, n,
+	                   out, depth, batch_rays_per_lane(n));
 }
 
 void launch_arith(hipStream_t s, int op, const float *x, const float *y, float *out, uint64_t n)

@@ -21,7 +21,7 @@ struct Counters {
 	uint32_t pad;
 	unsigned long long rays, shadow_rays;
 	uint32_t n_ray[2 * kRayKinds * kShards];     // closest-hit queue lengths, [step parity][kind][shard]
-	uint32_t head[2 * kShards];                  // bounce-ray entries already handed to traversal waves, [step parity][shard]
+	uint32_t head[2 * kShards];                  // bounce-ray entries already drawn by traversal waves, [step parity][shard]
 	unsigned long long inner, tri, sph;     // RTA_RENDER_COUNT_WORK only
 };
 
@@ -55,7 +55,7 @@ struct RenderArgs {
 	uint32_t n_slots;
 	uint32_t *q_ray;               // closest-hit queues, [step parity][kind][shard][shard_cap] slot numbers
 	uint32_t shard_cap;            // entries per sub-queue, a multiple of the workgroup size
-	uint32_t rays_per_lane, refill_at;     // bounce-ray traversal: see intersect_pulling
+	uint32_t rays_per_lane, refill_at;     // bounce-ray traversal: see traverse_pulling
 	// occlusion queue, 3 per entry: (origin, limit) (direction, slot) (radiance, -)
 	float4 *shadow;
 	Counters *cnt;                 // this group's

@@ -412,4 +412,82 @@ RTA_DEV void traverse_dyn(const DeviceTree &tree, const Ray &ray, float limit, u
 	hit = tr.result();
 }
 
+// A wave works through more rays than it has lanes: rays differ widely in
+// length (bounce rays on the dragon: 41 node visits and primitive tests on
+// average, 95 at the 99th percentile), so a wave that took 64 of them and ran
+// until the last was through would keep 43 % of its lanes busy.  Here, whenever
+// `refill_at` lanes have run out of work, the wave stores their results and
+// hands them new rays:
+//   got = grab(want, first)     reserves up to `want` rays, numbered first..first+got-1
+//                               (wave-uniform; got < want means the source is dry)
+//   tag = load(i, ray, limit)   fetches ray number i; the tag comes back in
+//   store(tag, hit)             once the ray is through
+template <bool ANY, bool COUNT, bool TAME_ONLY, class Grab, class Load, class Store>
+RTA_DEV void traverse_pulling(const DeviceTree &tree, const uint32_t refill_at, uint32_t *stack, const int depth,
+                              WorkCount &work, Grab grab, Load load, Store store)
+{
+	Traversal<ANY, COUNT, TAME_ONLY> tr;
+	tr.rest();
+	uint32_t tag = 0;
+	bool loaded = false, dry = false;
+	for (;;) {
+		const unsigned long long idle = __ballot(!tr.more);
+		const uint32_t n_idle = (uint32_t)__popcll(idle);
+		if (!dry && n_idle >= refill_at) {
+			if (!tr.more && loaded) {
+				store(tag, tr.result());
+				loaded = false;
+			}
+			uint32_t first = 0;
+			const uint32_t got = grab(n_idle, first);
+			dry = got < n_idle;
+			const uint32_t rank =
+			    __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+			if (!tr.more && rank < got) {
+				Ray ray;
+				float limit;
+				tag = load(first + rank, ray, limit);
+				tr.start(tree, ray, limit);
+				loaded = true;
+			}
+		}
+		if (__ballot(tr.more) == 0) {
+			if (dry)
+				break;
+			continue;        // every lane idle and the source not known to be dry: the next trip refills
+		}
+		if (tr.more)
+			tr.step(tree, stack, depth, work);
+	}
+	if (loaded)
+		store(tag, tr.result());
+}
+
+// grab() for a wave that owns rays 0..count-1 outright
+struct OwnChunk {
+	uint32_t count, next;
+	RTA_DEV uint32_t operator()(uint32_t want, uint32_t &first)
+	{
+		const uint32_t got = count - next < want ? count - next : want;
+		first = next;
+		next += got;
+		return got;
+	}
+};
+
+// grab() for waves that share a list of `total` rays through a counter in memory
+struct SharedList {
+	uint32_t total;
+	uint32_t *head;
+	RTA_DEV uint32_t operator()(uint32_t want, uint32_t &first)
+	{
+		uint32_t base = 0;
+		if ((threadIdx.x & 63) == 0)
+			base = atomicAdd(head, want);
+		base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+		first = base;
+		return base < total ? (total - base < want ? total - base : want) : 0u;
+	}
+};
+
 }  // namespace rta

@@ -589,7 +589,15 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	const uint32_t n_blocks = (spp + sps - 1) / sps;
 	const uint32_t run_blocks = p->run_blocks > 0 ? std::min((uint32_t)p->run_blocks, n_blocks) : 1u;
 	const uint32_t n_runs = (n_blocks + run_blocks - 1) / run_blocks;
-	const uint64_t items64 = (uint64_t)n_tiles * n_runs;          // (tile, block run) pairs, one per wave at a time
+	// A wave's 64 lanes work on 64 / lane_blocks pixels of a tile (whole rows of it)
+	// x lane_blocks block runs: lanes on the same pixel cost the same, so the
+	// fewer pixels a wave spans the less its lanes wait for each other where the
+	// image changes (dragon's silhouette).  Needs enough runs to go round.
+	uint32_t lane_blocks = 1;
+	while (lane_blocks < 8 && lane_blocks * 2 <= n_runs)
+		lane_blocks *= 2;
+	const uint32_t n_groups = (n_runs + lane_blocks - 1) / lane_blocks;
+	const uint64_t items64 = (uint64_t)n_tiles * lane_blocks * n_groups;      // one per wave at a time
 	const size_t frame_px = (size_t)p->width * p->height;
 	rta_stats st;
 	memset(&st, 0, sizeof st);
@@ -661,6 +669,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	base.n_pad = n_pad;
 	base.n_blocks = n_blocks;
 	base.run_blocks = run_blocks;
+	base.lane_blocks = lane_blocks;
 	base.n_items = n_items;
 	base.spp = spp;
 	base.sps = sps;

@@ -337,20 +337,25 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 		A.w = __uint_as_float(done);
 	}
 
-	// the whole wave is through: draw the next (tile, block run)
+	// the whole wave is through: draw the next item
 	if (__ballot(state == kWaiting) == ~0ull) {
 		uint32_t got = 0;
 		if (lane == 0)
 			got = atomicAdd(a.next_item, 1u);
 		got = __shfl(got, 0);
 		if (got < a.n_items) {
-			const uint32_t run = got / a.n_tiles, tile = got - run * a.n_tiles;
-			const uint32_t padded = tile * 64 + lane;
+			// item -> (tile, part of the tile, group of block runs); the wave's lanes
+			// cover the part's 64 / lane_blocks pixels x lane_blocks block runs
+			const uint32_t rest = got / a.n_tiles, tile = got - rest * a.n_tiles;
+			const uint32_t part = rest % a.lane_blocks, group = rest / a.lane_blocks;
+			const uint32_t part_pixels = 64 / a.lane_blocks;
+			const uint32_t padded = tile * 64 + part * part_pixels + lane % part_pixels;
+			const uint32_t first = (group * a.lane_blocks + lane / part_pixels) * a.run_blocks;
 			const int32_t pixel = a.pixels[padded];
-			if (pixel >= 0) {
+			if (pixel >= 0 && first < a.n_blocks) {
 				M.x = (uint32_t)pixel;
-				M.y = run * a.run_blocks;
-				M.z = M.y + a.run_blocks < a.n_blocks ? M.y + a.run_blocks : a.n_blocks;
+				M.y = first;
+				M.z = first + a.run_blocks < a.n_blocks ? first + a.run_blocks : a.n_blocks;
 				M.w = padded;
 				a.meta[slot] = M;
 				rng = stream_seed(a.seed, M.x, M.y);

@@ -64,8 +64,9 @@ struct RenderArgs {
 	float4 *partial;               // block sums, [block][padded pixel]
 	const int32_t *pixels;         // this shard's pixels, 64 per tile, -1 where a tile leaves the frame
 	uint32_t n_tiles, n_pad;       // n_pad = 64 * n_tiles
-	uint32_t n_blocks, run_blocks; // sample blocks per pixel; blocks a wave takes at once
-	uint32_t n_items;              // n_tiles * ceil(n_blocks / run_blocks)
+	uint32_t n_blocks, run_blocks; // sample blocks per pixel; consecutive blocks a lane works through per item
+	uint32_t lane_blocks;          // block runs a wave works on side by side (1, 2, 4 or 8), on 64 / lane_blocks pixels
+	uint32_t n_items;              // n_tiles * lane_blocks * ceil(n_blocks / (run_blocks * lane_blocks))
 	uint32_t spp, sps;
 	uint32_t width;
 	uint32_t seed;

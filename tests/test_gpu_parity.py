@@ -146,6 +146,9 @@ RENDER_CASES = [
     ("cornell_box.txt", 33, 17, 7, 3, 128),       # short last block
     ("dragon.txt", 96, 54, 8, 4, 0),
     ("dragon.txt", 40, 40, 3, 2, 256),
+    # many blocks per pixel: a wave's lanes share 32, 16 and 8 pixels (block runs side by side)
+    ("cornell_box.txt", 37, 21, 6, 1, 0),         # 6 blocks -> 4 at a time, the second group half empty
+    ("dragon.txt", 48, 40, 17, 2, 512),           # 9 blocks -> 8 at a time, ragged last block and group
 ]
 
 

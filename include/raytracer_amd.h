@@ -136,6 +136,15 @@ int rta_create(int device, rta_context **out);
 void rta_destroy(rta_context *ctx);
 const char *rta_last_error(const rta_context *ctx);
 
+/* The same tree as rta_scene_build_bvh - node numbering, boxes and primitive
+ * order bit for bit - built on the context's GPU (BuildBVH, src/main.cpp:133-248:
+ * level by level, the two-pointer partition of src/main.cpp:201-210 in closed
+ * form).  Meant for large inputs: 10 M triangles take seconds on the host.  The
+ * scene ends up exactly as after rta_scene_build_bvh; scenes with non-finite
+ * coordinates are handed to the host builder.  *device_ms (optional) receives
+ * the time of the build kernels, 0 when the host builder ran. */
+int rta_scene_build_bvh_device(rta_context *ctx, rta_scene *scene, float *device_ms);
+
 /* Validates the description (index ranges, tree shape, depth <= 64, every
  * primitive in exactly one leaf) and builds the device layouts.  Replaces the
  * hand-over of `Scene`/`BVHTree` to the render loop (src/main.cpp:607-615). */

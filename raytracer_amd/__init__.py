@@ -81,6 +81,7 @@ _SIGNATURES = {
     "rta_scene_from_triangles": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]),
     "rta_scene_free": (None, [C.c_void_p]),
     "rta_scene_build_bvh": (C.c_int, [C.c_void_p]),
+    "rta_scene_build_bvh_device": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
     "rta_scene_get_settings": (C.c_int, [C.c_void_p, C.POINTER(SceneSettings)]),
     "rta_scene_set_settings": (C.c_int, [C.c_void_p, C.POINTER(SceneSettings)]),
     "rta_scene_describe": (C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),
@@ -190,6 +191,13 @@ class Scene:
             raise RtaError(rc, _global_error())
         self.built = True
         return self
+
+    def build_bvh_on(self, ctx):
+        """The same tree, built on ctx's GPU; returns the build kernels' time in ms."""
+        ms = C.c_float(0)
+        ctx._check(lib().rta_scene_build_bvh_device(ctx._h, self._h, C.byref(ms)))
+        self.built = True
+        return ms.value
 
     @property
     def settings(self):

@@ -7,10 +7,6 @@
 
 #include "host_scene.hpp"
 
-struct rta_scene {
-	rta::HostScene *impl;
-};
-
 namespace rta {
 
 namespace {

@@ -85,7 +85,12 @@ int main(int argc, char **argv)
 		fprintf(stderr, "%s\n", err);
 		return 1;
 	}
-	if ((rc = rta_scene_build_bvh(scene)) != RTA_OK) {
+	// the reference builder's tree, built on the first GPU (on the host if that fails)
+	rta_context *builder = nullptr;
+	rc = rta_create(0, &builder) == RTA_OK ? rta_scene_build_bvh_device(builder, scene, nullptr) : RTA_E_NO_DEVICE;
+	if (builder)
+		rta_destroy(builder);
+	if (rc != RTA_OK && (rc = rta_scene_build_bvh(scene)) != RTA_OK) {
 		fprintf(stderr, "ERROR: %s\n", rta_global_error());
 		return 1;
 	}

@@ -12,6 +12,8 @@
 #include <string>
 #include <vector>
 
+#include "bvh_build.hpp"
+#include "host_scene.hpp"
 #include "kernels.hpp"
 
 namespace rta {
@@ -388,6 +390,43 @@ int rta_validate_scene(const rta_scene_desc *desc, char *err, size_t errlen)
 	if (err && errlen)
 		snprintf(err, errlen, "%s", problem.c_str());
 	return RTA_E_INVALID;
+}
+
+int rta_scene_build_bvh_device(rta_context *ctx, rta_scene *scene, float *device_ms)
+{
+	if (!ctx)
+		return RTA_E_INVALID;
+	if (!scene)
+		return ctx->fail(RTA_E_INVALID, "null scene");
+	if (device_ms)
+		*device_ms = 0;
+	HostScene &sc = *scene->impl;
+	if (sc.prim_count() == 0)
+		return ctx->fail(RTA_E_INVALID, "scene has no primitives");
+	if (!sc.perm.empty())
+		return ctx->fail(RTA_E_INVALID, "BVH already built for this scene");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	try {
+		BuiltTree tree;
+		bool unsupported = false;
+		const std::string err =
+		    device_build_bvh(ctx->stream, sc.prim_count(), sc.prim_type.data(), sc.geom.data(), tree, unsupported);
+		if (unsupported) {
+			sc.build_bvh();
+			return RTA_OK;
+		}
+		if (!err.empty())
+			return ctx->fail(RTA_E_DEVICE, "BVH build: " + err);
+		sc.adopt_tree(std::move(tree.perm), std::move(tree.node_bounds), std::move(tree.node_index),
+		              std::move(tree.node_count));
+		if (device_ms)
+			*device_ms = tree.device_ms;
+		return RTA_OK;
+	} catch (const SceneError &e) {
+		return ctx->fail(e.code, e.text);
+	} catch (const std::exception &e) {
+		return ctx->fail(RTA_E_INVALID, e.what());
+	}
 }
 
 int rta_upload_scene(rta_context *ctx, const rta_scene_desc *desc)

@@ -496,6 +496,19 @@ void permute_rows(std::vector<T> &a, const std::vector<int32_t> &order, size_t w
 	a.swap(out);
 }
 
+// Rows into BVH order; lights point at their primitive's new place (src/main.cpp:617-622).
+void finish_build(HostScene &sc)
+{
+	permute_rows(sc.prim_type, sc.perm, 1);
+	permute_rows(sc.prim_material, sc.perm, 1);
+	permute_rows(sc.prim_light, sc.perm, 1);
+	permute_rows(sc.geom, sc.perm, 9);
+	permute_rows(sc.normals, sc.perm, 9);
+	for (int32_t i = 0; i < sc.prim_count(); i++)
+		if (sc.prim_light[i] >= 0)
+			sc.light_prim[sc.prim_light[i]] = i;
+}
+
 }  // namespace
 
 void HostScene::build_bvh()
@@ -509,15 +522,21 @@ void HostScene::build_bvh()
 	}
 	Builder b(*this);
 	b.run();
-	permute_rows(prim_type, perm, 1);
-	permute_rows(prim_material, perm, 1);
-	permute_rows(prim_light, perm, 1);
-	permute_rows(geom, perm, 9);
-	permute_rows(normals, perm, 9);
-	// src/main.cpp:617-622
-	for (int32_t i = 0; i < prim_count(); i++)
-		if (prim_light[i] >= 0)
-			light_prim[prim_light[i]] = i;
+	finish_build(*this);
+}
+
+void HostScene::adopt_tree(std::vector<int32_t> &&order, std::vector<float> &&bounds, std::vector<int32_t> &&index,
+                           std::vector<int32_t> &&count)
+{
+	if (!perm.empty())
+		throw SceneError{RTA_E_INVALID, "BVH already built for this scene"};
+	if ((int32_t)order.size() != prim_count() || index.size() != count.size() || bounds.size() != index.size() * 6)
+		throw SceneError{RTA_E_INVALID, "tree does not fit the scene"};
+	perm = std::move(order);
+	node_bounds = std::move(bounds);
+	node_index = std::move(index);
+	node_count = std::move(count);
+	finish_build(*this);
 }
 
 void HostScene::describe(rta_scene_desc *out) const

@@ -36,6 +36,10 @@ struct HostScene {
 	void add_triangle(const float v[9], int32_t material);
 	void add_sphere(const float center[3], float radius, int32_t material);
 	void build_bvh();
+	// Takes a tree built elsewhere for the primitives in their current (file)
+	// order and finishes as build_bvh() does: rows into BVH order, lights re-linked.
+	void adopt_tree(std::vector<int32_t> &&order, std::vector<float> &&bounds, std::vector<int32_t> &&index,
+	                std::vector<int32_t> &&count);
 	void describe(rta_scene_desc *out) const;
 };
 
@@ -47,3 +51,8 @@ void camera_from_settings(const rta_scene_settings &s, rta_camera *out);
 int write_bmp(const char *path, int32_t w, int32_t h, const uint8_t *bgr);
 
 }  // namespace rta
+
+// The opaque handle of include/raytracer_amd.h.
+struct rta_scene {
+	rta::HostScene *impl;
+};

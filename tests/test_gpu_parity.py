@@ -327,3 +327,74 @@ def test_design_variants_return_the_same_bits(gpu):
         got = ht.cpu().numpy()
         assert np.array_equal(got[:, 0].view(np.int32), want["prim"]), variant
         assert np.array_equal(got[:, 1].view(np.uint32), want["t"].view(np.uint32)), variant
+
+
+def _same_tree(a, b):
+    """Every array of the built scene, bit for bit (boxes compared as bits: signed zeros count)."""
+    aa, bb = a.arrays(), b.arrays()
+    for key in aa:
+        x, y = aa[key], bb[key]
+        if x.dtype == np.float32:
+            x, y = x.view(np.uint32), y.view(np.uint32)
+        assert np.array_equal(x, y), key
+    assert np.array_equal(a.permutation(), b.permutation())
+
+
+def test_device_bvh_build_is_the_host_tree(gpu):
+    """The GPU builder reproduces the reference builder's tree exactly: node
+    numbering, boxes, primitive order, light links - on the shipped scenes, on
+    spheres, on inputs whose splits fail, on signed zeros and on a 300 k soup."""
+    for name in ("cornell_box.txt", "dragon.txt"):
+        path = f"{orc.SCENES}/{name}"
+        host = rta.Scene.load(path).build_bvh()
+        dev = rta.Scene.load(path)
+        dev.build_bvh_on(gpu)
+        _same_tree(host, dev)
+    rng = np.random.default_rng(3)
+    cases = {
+        "one": rng.uniform(-1, 1, (1, 9)),
+        "two": rng.uniform(-1, 1, (2, 9)),
+        "three": rng.uniform(-1, 1, (3, 9)),
+        # identical centroids: every split fails after permuting the range
+        "coincident": np.tile(rng.uniform(-1, 1, (1, 9)), (37, 1)),
+        # half of the centroids coincide: large leaves next to ordinary subtrees
+        "half coincident": np.concatenate([np.tile(rng.uniform(-1, 1, (1, 9)), (500, 1)), rng.uniform(-1, 1, (700, 9))]),
+        # coordinates that are +0 and -0: the boxes must carry the same sign bits
+        "signed zeros": np.where(rng.random((4000, 9)) < 0.3, np.where(rng.random((4000, 9)) < 0.5, 0.0, -0.0),
+                                 rng.uniform(-1, 1, (4000, 9))),
+        # a grid: many equal coordinates and centroids exactly on split planes
+        "grid": (rng.integers(0, 8, (5000, 1, 3)) + rng.integers(0, 2, (5000, 3, 3))).reshape(5000, 9) / 4.0,
+        "soup": (rng.uniform(-1, 1, (300_000, 1, 3)) + rng.uniform(-0.01, 0.01, (300_000, 3, 3))).reshape(-1, 9),
+    }
+    for label, tri in cases.items():
+        tri = np.ascontiguousarray(tri, np.float32)
+        host = rta.Scene.from_triangles(tri).build_bvh()
+        dev = rta.Scene.from_triangles(tri)
+        ms = dev.build_bvh_on(gpu)
+        assert ms > 0, label
+        try:
+            _same_tree(host, dev)
+        except AssertionError as e:
+            raise AssertionError(f"{label}: {e}")
+    # spheres and triangles mixed, through the scene grammar
+    text = orc.scene_variant("cornell_box.txt", 32, 32, 1)
+    for k in range(40):
+        c = rng.uniform(-1, 1, 3)
+        text += f"\nsphere {{ center [{c[0]:.5f} {c[1]:.5f} {c[2]:.5f}] radius {rng.uniform(0.01, 0.2):.5f} }}\n"
+    host = rta.Scene.parse(text).build_bvh()
+    dev = rta.Scene.parse(text)
+    dev.build_bvh_on(gpu)
+    _same_tree(host, dev)
+    # a tree built on the device renders like the host's
+    gpu.upload(dev)
+    a = gpu.render_scene(dev, seed=5)[1]
+    gpu.upload(host)
+    b = gpu.render_scene(host, seed=5)[1]
+    assert np.array_equal(bits(a), bits(b))
+    # non-finite coordinates go to the host builder
+    bad = np.ascontiguousarray(rng.uniform(-1, 1, (10, 9)), np.float32)
+    bad[3, 4] = np.nan
+    host = rta.Scene.from_triangles(bad).build_bvh()
+    dev = rta.Scene.from_triangles(bad)
+    assert dev.build_bvh_on(gpu) == 0
+    _same_tree(host, dev)

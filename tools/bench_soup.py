@@ -4,8 +4,9 @@ and incoherent ray batches resident in HBM, closest-hit through the C ABI.
 
     python tools/bench_soup.py [--tris 10000000] [--rays 67108864] [--check 1048576]
 
-The tree is the reference builder's (restated in rta_scene_build_bvh; the
-reference binary itself stops at 16384 objects).  Correctness: a strided subset
+The tree is the reference builder's, built on the GPU
+(rta_scene_build_bvh_device) and compared with the host builder's
+(rta_scene_build_bvh; the reference binary itself stops at 16384 objects).  Correctness: a strided subset
 of each batch is traced by the CPU checker and must agree bit for bit in
 primitive index and t; a checksum over all indices is printed.
 """
@@ -62,17 +63,34 @@ def main():
     ap.add_argument("--rays", type=int, default=64 * 1024 * 1024)
     ap.add_argument("--check", type=int, default=1 << 20, help="rays per batch verified against the CPU checker")
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--no-host-build", action="store_true", help="skip the host builder's comparison tree")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
 
-    t0 = time.perf_counter()
     soup = make_soup(args.tris)
-    scene = rta.Scene.from_triangles(soup).build_bvh()
-    build_s = time.perf_counter() - t0
-    d = scene.desc()
     ctx = rta.Context(0)
+    # the reference builder's tree, built on the GPU ...
+    scene = rta.Scene.from_triangles(soup)
+    t0 = time.perf_counter()
+    kernel_ms = scene.build_bvh_on(ctx)
+    device_s = time.perf_counter() - t0
+    d = scene.desc()
+    print(f"soup: {d.n_prims} triangles, {d.n_nodes} nodes; tree built on the GPU in {kernel_ms:.1f} ms of kernels, "
+          f"{device_s:.2f} s with transfers and the host-side reordering of the scene arrays", flush=True)
+    build = {"device_kernels_ms": kernel_ms, "device_call_s": device_s}
+    if not args.no_host_build:
+        # ... and by the host builder, which must give the same arrays
+        other = rta.Scene.from_triangles(soup)
+        t0 = time.perf_counter()
+        other.build_bvh()
+        build["host_call_s"] = time.perf_counter() - t0
+        a, b = scene.arrays(), other.arrays()
+        build["same_tree"] = bool(all(np.array_equal(a[k].view(np.uint32) if a[k].dtype == np.float32 else a[k],
+                                                     b[k].view(np.uint32) if b[k].dtype == np.float32 else b[k])
+                                      for k in a) and np.array_equal(scene.permutation(), other.permutation()))
+        print(f"host builder: {build['host_call_s']:.2f} s, same tree: {build['same_tree']}", flush=True)
+        del other, a, b
     ctx.upload(scene)
-    print(f"soup: {d.n_prims} triangles, {d.n_nodes} nodes, parse+build {build_s:.1f} s", flush=True)
 
     checker = None
     if args.check:
@@ -83,7 +101,7 @@ def main():
 
     side = int(round(args.rays ** 0.5))
     batches = {"coherent": coherent_rays(side, dev), "incoherent": incoherent_rays(args.rays, dev)}
-    report = {"triangles": int(d.n_prims), "nodes": int(d.n_nodes), "batches": {}}
+    report = {"triangles": int(d.n_prims), "nodes": int(d.n_nodes), "build": build, "batches": {}}
     for name, rays in batches.items():
         n = rays.shape[0]
         hits = torch.empty((n, 4), dtype=torch.float32, device=dev)
@@ -117,7 +135,7 @@ def main():
         print(name, json.dumps(entry), flush=True)
         del hits
     print(json.dumps(report))
-    ok = all(b.get("bit_exact", True) for b in report["batches"].values())
+    ok = all(b.get("bit_exact", True) for b in report["batches"].values()) and build.get("same_tree", True)
     sys.exit(0 if ok else 1)
 
 

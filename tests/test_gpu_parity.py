@@ -398,3 +398,23 @@ def test_device_bvh_build_is_the_host_tree(gpu):
     dev = rta.Scene.from_triangles(bad)
     assert dev.build_bvh_on(gpu) == 0
     _same_tree(host, dev)
+
+
+def test_cli_writes_the_same_image(gpu, tmp_path):
+    """`raytracer FILE` -> ./image.bmp: the file the library path would write
+    (the CLI builds its tree on the GPU, this test on the host)."""
+    import subprocess
+    text = orc.scene_variant("cornell_box.txt", 52, 30, 6)
+    (tmp_path / "scene.txt").write_text(text)
+    p = subprocess.run([rta.CLI_PATH, "scene.txt", "--seed", "77", "--samples-per-stream", "4"], cwd=tmp_path,
+                       stderr=subprocess.PIPE, text=True, timeout=100)
+    assert p.returncode == 0, p.stderr
+    psc = rta.Scene.parse(text).build_bvh()
+    gpu.upload(psc)
+    bgr = gpu.render_scene(psc, seed=77, samples_per_stream=4)[0]
+    rta.write_bmp(str(tmp_path / "want.bmp"), bgr)
+    assert (tmp_path / "image.bmp").read_bytes() == (tmp_path / "want.bmp").read_bytes()
+    # and within Monte-Carlo noise of the reference binary's own render of the scene
+    want = orc.Scene.parse(text).build_bvh().render(orc.RNG_ROW, orc.MATH_LIBM)[0]
+    diff = bgr.astype(np.float64) - want.astype(np.float64)
+    assert np.sqrt((diff ** 2).mean()) < 40.0

@@ -2,7 +2,10 @@
 """Intersect-only microbenchmark: a seed-fixed random triangle soup, coherent
 and incoherent ray batches resident in HBM, closest-hit through the C ABI.
 
-    python tools/bench_soup.py [--tris 10000000] [--rays 67108864] [--check 1048576]
+    python tests/soup_bench.py [--tris 10000000] [--rays 67108864] [--check 1048576]
+
+(It lives under tests/ because it checks against the CPU checker; pytest does
+not collect it.)
 
 The tree is the reference builder's, built on the GPU
 (rta_scene_build_bvh_device) and compared with the host builder's
@@ -90,7 +93,10 @@ def main():
                                       for k in a) and np.array_equal(scene.permutation(), other.permutation()))
         print(f"host builder: {build['host_call_s']:.2f} s, same tree: {build['same_tree']}", flush=True)
         del other, a, b
+    t0 = time.perf_counter()
     ctx.upload(scene)
+    build["upload_s"] = time.perf_counter() - t0
+    print(f"validated, flattened and uploaded in {build['upload_s']:.2f} s", flush=True)
 
     checker = None
     if args.check:

@@ -185,7 +185,8 @@ typedef struct {
 
 enum {
 	RTA_RENDER_TIME_KERNELS = 1,   /* bracket every intersect launch with HIP events (stats.intersect_ms) */
-	RTA_RENDER_COUNT_WORK = 2      /* count node visits / primitive tests (slower kernels) */
+	RTA_RENDER_COUNT_WORK = 2,     /* count node visits / primitive tests (slower kernels) */
+	RTA_RENDER_SMALL_PASSES = 4    /* hold as few sample blocks in memory at a time as possible (see rta_render) */
 };
 
 typedef struct {
@@ -208,6 +209,10 @@ typedef struct {
  * h ^= h>>16 }.  A block's samples are summed in order starting from 0, and a
  * pixel's block sums are summed in block order starting from 0, all in fp32,
  * so the result does not depend on scheduling, slot count or sharding.
+ * Memory: a block's sum waits (16 bytes per pixel and block) until the pixel's
+ * earlier blocks are in; when all blocks together would need more than 32 GiB
+ * they are rendered in passes over consecutive blocks (RTA_RENDER_SMALL_PASSES:
+ * always, in the smallest passes), with the same sums.
  * accum: height*width*3 floats, per-pixel radiance SUM over samples (may be
  * NULL); bgr: height*width*3 bytes B,G,R top row first (may be NULL).  Only the
  * pixels owned by this shard are written. */

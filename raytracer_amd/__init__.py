@@ -19,7 +19,7 @@ CLI_PATH = os.path.join(_HERE, "raytracer")
 
 MEM_HOST, MEM_DEVICE = 0, 1
 PRIM_TRIANGLE, PRIM_SPHERE = 0, 1
-RENDER_TIME_KERNELS, RENDER_COUNT_WORK = 1, 2
+RENDER_TIME_KERNELS, RENDER_COUNT_WORK, RENDER_SMALL_PASSES = 1, 2, 4
 
 OK = 0
 E_INVALID, E_PARSE, E_IO, E_NO_DEVICE, E_DEVICE, E_NO_SCENE, E_LIMIT = -1, -2, -3, -4, -5, -6, -7

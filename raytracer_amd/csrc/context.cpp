@@ -671,7 +671,15 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	HIP_TRY(ctx, ctx->q_ray.reserve(group_queue * groups * 4));
 	if (ctx->n_lights > 0)
 		HIP_TRY(ctx, ctx->shadow.reserve(S * 48));
-	HIP_TRY(ctx, ctx->partial.reserve(std::max<size_t>((size_t)n_blocks * n_pad, 1) * 16));
+	// Block sums are kept until their pixel's earlier blocks are in, 16 bytes per
+	// (pixel, block).  Beyond the budget the samples are rendered in passes over
+	// consecutive groups of blocks, each pass continuing the pixels' sums.
+	const uint64_t budget = (p->flags & RTA_RENDER_SMALL_PASSES) ? 0 : (uint64_t)32 << 30;
+	const uint32_t blocks_per_group = lane_blocks * run_blocks;
+	const uint64_t bytes_per_group = (uint64_t)blocks_per_group * std::max<uint32_t>(n_pad, 1) * 16;
+	const uint32_t groups_per_pass = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_groups, budget / bytes_per_group));
+	const uint32_t pass_blocks = std::min<uint64_t>(n_blocks, (uint64_t)groups_per_pass * blocks_per_group);
+	HIP_TRY(ctx, ctx->partial.reserve(std::max<size_t>((size_t)pass_blocks * n_pad, 1) * 16));
 	HIP_TRY(ctx, ctx->pixels.reserve(std::max<size_t>(n_pad, 1) * 4));
 
 	const bool to_device = p->out_mem == RTA_MEM_DEVICE;
@@ -709,7 +717,6 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	base.n_blocks = n_blocks;
 	base.run_blocks = run_blocks;
 	base.lane_blocks = lane_blocks;
-	base.n_items = n_items;
 	base.spp = spp;
 	base.sps = sps;
 	base.width = (uint32_t)p->width;
@@ -768,26 +775,15 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 
 	if (n_pad)
 		HIP_TRY_R(hipMemcpyAsync(ctx->pixels.ptr, px.data(), (size_t)n_pad * 4, hipMemcpyHostToDevice, s));
-	for (int g = 0; g < kMaxGroups; g++) {
-		memset(&ctx->host_counters[g], 0, sizeof(Counters));
-		ctx->host_counters[g].live = g < groups ? group_slots / 64 : 0;
-	}
-	HIP_TRY_R(hipMemcpyAsync(ctx->counters.ptr, ctx->host_counters, sizeof(Counters) * kMaxGroups, hipMemcpyHostToDevice, s));
-	HIP_TRY_R(hipStreamSynchronize(s));       // host_counters is reused for read-back below
-
 	HIP_TRY_R(hipEventRecord(ev_begin, s));
 	for (int g = 1; g < groups; g++)
 		HIP_TRY_R(hipStreamWaitEvent(gs[g], ev_begin, 0));
-	for (int g = 0; g < groups; g++)
-		launch_init_slots(gs[g], ga[g], group_slots);
-
 	// The wavefront loop.  Progress lives on the device; the host reads it back
 	// every `poll` steps only to notice the end (steps past the end find every
 	// slot retired and do nothing).  The groups' steps are issued round-robin on
 	// their own streams and run concurrently.
 	const int poll = 16;
 	uint64_t steps = 0;
-	bool done = n_items == 0;
 	auto timed = [&](hipStream_t st_, int kind, auto &&launch) -> hipError_t {
 		if (!time_kernels) {
 			launch();
@@ -807,37 +803,61 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		launch();
 		return hipEventRecord(e1, st_);
 	};
-	while (!done) {
-		for (int k = 0; k < poll; k++) {
-			for (int g = 0; g < groups; g++) {
-				const RenderArgs &a = ga[g];
-				const int par = (int)(steps & 1);
-				// advance queues the step's rays; shadow comes before intersect, whose
-				// first workgroup empties the occlusion queue for the next step
-				launch_advance(gs[g], a, par);
-				if (lights)
-					HIP_TRY_R(timed(gs[g], 1, [&] { launch_shadow(gs[g], a, group_slots, ctx->stack_depth, count_work); }));
-				HIP_TRY_R(timed(gs[g], 0, [&] { launch_intersect(gs[g], a, par, ctx->stack_depth, count_work); }));
-			}
-			steps++;
+	for (uint32_t g0 = 0; g0 < n_groups && n_items; g0 += groups_per_pass) {
+		const uint32_t g1 = std::min(n_groups, g0 + groups_per_pass);
+		const uint32_t first_block = g0 * blocks_per_group;
+		const uint32_t end_block = std::min<uint64_t>(n_blocks, (uint64_t)g1 * blocks_per_group);
+		for (int g = 0; g < kMaxGroups; g++) {
+			memset(&ctx->host_counters[g], 0, sizeof(Counters));
+			ctx->host_counters[g].live = g < groups ? group_slots / 64 : 0;
 		}
-		HIP_TRY_R(hipGetLastError());
-		for (int g = 0; g < groups; g++)
-			HIP_TRY_R(hipMemcpyAsync(&ctx->host_counters[g], ctx->counters.as<Counters>() + g, sizeof(Counters),
-			                         hipMemcpyDeviceToHost, gs[g]));
-		done = true;
+		HIP_TRY_R(hipMemcpyAsync(ctx->counters.ptr, ctx->host_counters, sizeof(Counters) * kMaxGroups, hipMemcpyHostToDevice, s));
+		HIP_TRY_R(hipStreamSynchronize(s));       // host_counters is reused for read-back below; the groups are idle
 		for (int g = 0; g < groups; g++) {
-			HIP_TRY_R(hipStreamSynchronize(gs[g]));
-			done = done && ctx->host_counters[g].live == 0;
+			ga[g].first_group = g0;
+			ga[g].first_block = first_block;
+			ga[g].n_items = n_tiles * lane_blocks * (g1 - g0);
+			launch_init_slots(gs[g], ga[g], group_slots);
 		}
+		bool done = false;
+		while (!done) {
+			for (int k = 0; k < poll; k++) {
+				for (int g = 0; g < groups; g++) {
+					const RenderArgs &a = ga[g];
+					const int par = (int)(steps & 1);
+					// advance queues the step's rays; shadow comes before intersect, whose
+					// first workgroup empties the occlusion queue for the next step
+					launch_advance(gs[g], a, par);
+					if (lights)
+						HIP_TRY_R(timed(gs[g], 1, [&] { launch_shadow(gs[g], a, group_slots, ctx->stack_depth, count_work); }));
+					HIP_TRY_R(timed(gs[g], 0, [&] { launch_intersect(gs[g], a, par, ctx->stack_depth, count_work); }));
+				}
+				steps++;
+			}
+			HIP_TRY_R(hipGetLastError());
+			for (int g = 0; g < groups; g++)
+				HIP_TRY_R(hipMemcpyAsync(&ctx->host_counters[g], ctx->counters.as<Counters>() + g, sizeof(Counters),
+				                         hipMemcpyDeviceToHost, gs[g]));
+			done = true;
+			for (int g = 0; g < groups; g++) {
+				HIP_TRY_R(hipStreamSynchronize(gs[g]));
+				done = done && ctx->host_counters[g].live == 0;
+			}
+		}
+		for (int g = 0; g < groups; g++) {
+			const Counters &c = ctx->host_counters[g];
+			st.rays += c.rays;
+			st.shadow_rays += c.shadow_rays;
+			st.inner_visits += c.inner;
+			st.tri_tests += c.tri;
+			st.sph_tests += c.sph;
+		}
+		// all groups are idle here (synchronised above)
+		if (d_frame && n_owned)
+			launch_sum_blocks(s, base.partial, base.pixels, n_pad, end_block - first_block, d_frame, g0 > 0);
 	}
-
-	// all groups are idle here (synchronised above)
-	if (d_frame && n_owned) {
-		launch_sum_blocks(s, base.partial, base.pixels, n_pad, n_blocks, d_frame);
-		if (d_bgr)
-			launch_resolve(s, d_frame, base.pixels, n_pad, (float)spp, p->exposure, d_bgr);
-	}
+	if (d_frame && d_bgr && n_owned)
+		launch_resolve(s, d_frame, base.pixels, n_pad, (float)spp, p->exposure, d_bgr);
 	HIP_TRY_R(hipEventRecord(ev_end, s));
 	HIP_TRY_R(hipGetLastError());
 	HIP_TRY_R(hipStreamSynchronize(s));
@@ -877,14 +897,6 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		}
 	}
 	st.samples = (uint64_t)n_owned * spp;
-	for (int g = 0; g < groups; g++) {
-		const Counters &c = ctx->host_counters[g];
-		st.rays += c.rays;
-		st.shadow_rays += c.shadow_rays;
-		st.inner_visits += c.inner;
-		st.tri_tests += c.tri;
-		st.sph_tests += c.sph;
-	}
 	st.steps = steps;
 	if (stats)
 		*stats = st;

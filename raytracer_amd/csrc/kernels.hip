@@ -322,7 +322,7 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 		const uint32_t len = a.spp - first < a.sps ? a.spp - first : a.sps;
 		need_ray = true;
 		if (done >= len) {
-			a.partial[(size_t)M.y * a.n_pad + M.w] = make_float4(A.x, A.y, A.z, 0.f);
+			a.partial[(size_t)(M.y - a.first_block) * a.n_pad + M.w] = make_float4(A.x, A.y, A.z, 0.f);
 			A = make_float4(0.f, 0.f, 0.f, 0.f);
 			done = 0;
 			M.y++;
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 			// item -> (tile, part of the tile, group of block runs); the wave's lanes
 			// cover the part's 64 / lane_blocks pixels x lane_blocks block runs
 			const uint32_t rest = got / a.n_tiles, tile = got - rest * a.n_tiles;
-			const uint32_t part = rest % a.lane_blocks, group = rest / a.lane_blocks;
+			const uint32_t part = rest % a.lane_blocks, group = a.first_group + rest / a.lane_blocks;
 			const uint32_t part_pixels = 64 / a.lane_blocks;
 			const uint32_t padded = tile * 64 + part * part_pixels + lane % part_pixels;
 			const uint32_t first = (group * a.lane_blocks + lane / part_pixels) * a.run_blocks;
@@ -528,10 +528,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 
 // ------------------------------------------------------------------ finish
 
-// Pixel sum = block sums added in block order from zero.  `pixels` is the
-// padded per-tile list (64 entries per tile, -1 where the tile leaves the frame).
+// Pixel sum = block sums added in block order from zero (`resume`: from the sum
+// of the blocks before these).  `pixels` is the padded per-tile list (64 entries
+// per tile, -1 where the tile leaves the frame).
 __global__ __launch_bounds__(kBlock) void k_sum_blocks(const float4 *partial, const int32_t *pixels, uint32_t n_pad,
-                                                       uint32_t n_blocks, float *frame)
+                                                       uint32_t n_blocks, float *frame, bool resume)
 {
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
 	if (i >= n_pad)
@@ -539,14 +540,19 @@ __global__ __launch_bounds__(kBlock) void k_sum_blocks(const float4 *partial, co
 	const int32_t pixel = pixels[i];
 	if (pixel < 0)
 		return;
+	float *dst = frame + (size_t)pixel * 3;
 	float x = 0, y = 0, z = 0;
+	if (resume) {
+		x = dst[0];
+		y = dst[1];
+		z = dst[2];
+	}
 	for (uint32_t b = 0; b < n_blocks; b++) {
 		const float4 p = partial[(size_t)b * n_pad + i];
 		x += p.x;
 		y += p.y;
 		z += p.z;
 	}
-	float *dst = frame + (size_t)pixel * 3;
 	dst[0] = x;
 	dst[1] = y;
 	dst[2] = z;
@@ -717,10 +723,10 @@ void launch_shadow(hipStream_t s, const RenderArgs &a, uint32_t bound, int depth
 }
 
 void launch_sum_blocks(hipStream_t s, const float4 *partial, const int32_t *pixels, uint32_t n_pad, uint32_t n_blocks,
-                       float *frame)
+                       float *frame, bool resume)
 {
 	hipLaunchKernelGGL(k_sum_blocks, dim3(blocks_for(n_pad)), dim3(kBlock), 0, s, partial, pixels, n_pad, n_blocks,
-	                   frame);
+	                   frame, resume);
 }
 
 void launch_resolve(hipStream_t s, const float *frame, const int32_t *pixels, uint32_t n, float samples, float exposure,

@@ -61,12 +61,13 @@ struct RenderArgs {
 	Counters *cnt;                 // this group's
 	uint32_t *next_item;           // shared by all groups
 
-	float4 *partial;               // block sums, [block][padded pixel]
+	float4 *partial;               // block sums of the pass, [block - first_block][padded pixel]
 	const int32_t *pixels;         // this shard's pixels, 64 per tile, -1 where a tile leaves the frame
 	uint32_t n_tiles, n_pad;       // n_pad = 64 * n_tiles
 	uint32_t n_blocks, run_blocks; // sample blocks per pixel; consecutive blocks a lane works through per item
 	uint32_t lane_blocks;          // block runs a wave works on side by side (1, 2, 4 or 8), on 64 / lane_blocks pixels
-	uint32_t n_items;              // n_tiles * lane_blocks * ceil(n_blocks / (run_blocks * lane_blocks))
+	uint32_t n_items;              // of the pass: n_tiles * lane_blocks * its groups of lane_blocks block runs
+	uint32_t first_group, first_block;     // where the pass starts
 	uint32_t spp, sps;
 	uint32_t width;
 	uint32_t seed;
@@ -80,7 +81,7 @@ void launch_advance(hipStream_t s, const RenderArgs &a, int par);
 void launch_intersect(hipStream_t s, const RenderArgs &a, int par, int depth, bool count);
 void launch_shadow(hipStream_t s, const RenderArgs &a, uint32_t bound, int depth, bool count);
 void launch_sum_blocks(hipStream_t s, const float4 *partial, const int32_t *pixels, uint32_t n_pad, uint32_t n_blocks,
-                       float *frame);
+                       float *frame, bool resume);
 void launch_resolve(hipStream_t s, const float *frame, const int32_t *pixels, uint32_t n, float samples, float exposure,
                     uint8_t *bgr);
 void launch_batch_closest(hipStream_t s, const TreeRef &tree, const float *rays, uint64_t n, rta_hit *hits, int depth,

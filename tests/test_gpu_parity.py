@@ -201,7 +201,8 @@ def test_scheduling_knobs_do_not_change_the_image(gpu):
     psc.set_render(40, 24, 6)
     gpu.upload(psc)
     base = gpu.render_scene(psc, seed=9, samples_per_stream=2)[1]
-    for kw in (dict(slots=64), dict(slots=100000, streams=1), dict(streams=8, run_blocks=3), dict(run_blocks=1, streams=2)):
+    for kw in (dict(slots=64), dict(slots=100000, streams=1), dict(streams=8, run_blocks=3), dict(run_blocks=1, streams=2),
+               dict(flags=rta.RENDER_SMALL_PASSES), dict(flags=rta.RENDER_SMALL_PASSES, run_blocks=2, slots=256)):
         other = gpu.render_scene(psc, seed=9, samples_per_stream=2, **kw)[1]
         assert np.array_equal(bits(other), bits(base)), kw
 

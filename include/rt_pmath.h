@@ -141,6 +141,33 @@ RT_PM_FN float pm_cosf(float xf)
 	return (float)v;
 }
 
+/*
+ * Both at once, with the bits of pm_sinf(x) and pm_cosf(x): the reduction and the
+ * two kernels are evaluated once and the quadrant only picks and negates, which
+ * on a SIMD machine avoids running both kernels for each of the two calls when
+ * neighbouring lanes fall into different quadrants.
+ */
+RT_PM_FN void pm_sincosf(float xf, float *s_out, float *c_out)
+{
+	double x = (double)xf;
+	if (!(x > -1e5 && x < 1e5)) {
+		*s_out = pm__nanf();
+		*c_out = pm__nanf();
+		return;
+	}
+	int q;
+	double r = pm__reduce_pio2(x, &q);
+	double sk = pm__sin_kernel(r), ck = pm__cos_kernel(r);
+	double sv = (q & 1) ? ck : sk;         /* q: 0 sin, 1 cos, 2 -sin, 3 -cos */
+	double cv = (q & 1) ? sk : ck;         /* q: 0 cos, 1 -sin, 2 -cos, 3 sin */
+	if (q & 2)
+		sv = -sv;
+	if (q == 1 || q == 2)
+		cv = -cv;
+	*s_out = (float)sv;
+	*c_out = (float)cv;
+}
+
 /* Natural log of a positive finite binary64 value (binary32 inputs widened to
  * binary64 are always normal there, so float subnormals need no special path). */
 RT_PM_FN double pm__log_pos(double x)

@@ -1256,6 +1256,8 @@ void orc_pmath(int which, const float *x, const float *y, float *out, int64_t n)
 		case 0: out[i] = pm_sinf(x[i]); break;
 		case 1: out[i] = pm_cosf(x[i]); break;
 		case 2: out[i] = pm_logf(x[i]); break;
+		case 4: { float c; pm_sincosf(x[i], &out[i], &c); break; }     /* the sine of the pair */
+		case 5: { float s; pm_sincosf(x[i], &s, &out[i]); break; }     /* the cosine of the pair */
 		default: out[i] = pm_powf(x[i], y[i]); break;
 		}
 	}

@@ -131,8 +131,10 @@ RTA_DEV Ray camera_ray(const RenderArgs &a, uint32_t slot, uint32_t pixel, uint3
 	} while (u1 == 0);
 	const float u2 = rng_float(rng);
 	const float radius = .5f * __builtin_sqrtf(-2 * pm_logf(u1));
-	const float ju = radius * pm_cosf(2 * kPiF * u2);
-	const float jv = radius * pm_sinf(2 * kPiF * u2);
+	float sj, cj;
+	pm_sincosf(2 * kPiF * u2, &sj, &cj);
+	const float ju = radius * cj;
+	const float jv = radius * sj;
 	const V3 ul = mk(a.cam.upper_left[0], a.cam.upper_left[1], a.cam.upper_left[2]);
 	const V3 du = mk(a.cam.du[0], a.cam.du[1], a.cam.du[2]);
 	const V3 dv = mk(a.cam.dv[0], a.cam.dv[1], a.cam.dv[2]);

@@ -28,8 +28,10 @@ RTA_DEV V3 sample_cosine(uint32_t &rng)
 	float r2 = rng_float(rng);
 	float phi = 2 * kPiF * r1;
 	float s = __builtin_sqrtf(r2);
-	float x = pm_cosf(phi) * s;
-	float y = pm_sinf(phi) * s;
+	float sp, cp;
+	pm_sincosf(phi, &sp, &cp);
+	float x = cp * s;
+	float y = sp * s;
 	float z = __builtin_sqrtf(1 - r2);
 	return mk(x, y, z);
 }
@@ -44,8 +46,10 @@ RTA_DEV V3 sample_vndf(V3 v, float alpha, uint32_t &rng)
 	float phi = 2 * kPiF * r1;
 	float z = __builtin_fmaf((1 - r2), (1 + vh.z), -vh.z);
 	float st = __builtin_sqrtf(lesser(1.f, greater(0.f, 1 - z * z)));
-	float x = st * pm_cosf(phi);
-	float y = st * pm_sinf(phi);
+	float sp, cp;
+	pm_sincosf(phi, &sp, &cp);
+	float x = st * cp;
+	float y = st * sp;
 	V3 h = mk(x, y, z) + vh;
 	V3 n = unit(mk(alpha * h.x, alpha * h.y, h.z));
 	return (n * 2.f) * dot(n, v) - v;

@@ -270,7 +270,7 @@ def pmath(which, x, y=None):
     x = f32(x)
     y = f32(y) if y is not None else np.zeros_like(x)
     out = np.empty_like(x)
-    lib().orc_pmath({"sin": 0, "cos": 1, "log": 2, "pow": 3}[which], x, y, out, x.size)
+    lib().orc_pmath({"sin": 0, "cos": 1, "log": 2, "pow": 3, "sincos_s": 4, "sincos_c": 5}[which], x, y, out, x.size)
     return out
 
 

@@ -28,6 +28,17 @@ def test_sin_cos():
         assert (d[big] == 0).mean() > 0.9999
 
 
+def test_sincos_pair_has_the_bits_of_the_single_functions():
+    """pm_sincosf is what the kernels call where the reference calls cosf and
+    sinf of one angle; the checker calls pm_sinf and pm_cosf."""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(0, 2 * np.pi, 500000), rng.uniform(-1000, 1000, 200000),
+                        [0, -0.0, np.pi / 2, np.pi, 3 * np.pi / 2, 2 * np.pi, 1e-8, 6.2831855, 1e6, np.inf, np.nan]]
+                       ).astype(np.float32)
+    assert np.array_equal(orc.pmath("sincos_s", x).view(np.uint32), orc.pmath("sin", x).view(np.uint32))
+    assert np.array_equal(orc.pmath("sincos_c", x).view(np.uint32), orc.pmath("cos", x).view(np.uint32))
+
+
 def test_log():
     rng = np.random.default_rng(1)
     x = np.concatenate([rng.random(400000), np.arange(1, 4097) / 2 ** 24, rng.uniform(1, 1e6, 50000),

@@ -396,9 +396,9 @@ struct Traversal {
 // unfinished lane exactly one unit of work (an inner-node visit or a primitive
 // test).  The loop condition is a wave-wide ballot: a convergent operation the
 // compiler may not duplicate into the two branches, which keeps this ONE loop
-// instead of a nest of "descend" and "leaf" loops in which lanes wait for the
-// slowest lane of each inner loop (measured: 23 % instead of 16 % of the lanes
-// active per vector instruction on bounce rays).
+// instead of a nest of "walk to a leaf" and "test the leaf" loops in which lanes
+// wait for the slowest lane of each inner loop (measured: 23 % instead of 16 % of
+// the lanes active per vector instruction on bounce rays).
 template <bool ANY, bool COUNT, bool TAME_ONLY = false>
 RTA_DEV void traverse_dyn(const DeviceTree &tree, const Ray &ray, float limit, uint32_t *stack, const int depth,
                           HitRec &hit, WorkCount &work)

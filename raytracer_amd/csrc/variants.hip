@@ -12,6 +12,13 @@
 //   4  two nested loops per ray (walk inner nodes down to a leaf, then test all
 //      of the leaf's primitives) instead of one loop whose every trip is one
 //      node visit or one primitive test
+//   100        not a variant but a census: per ray the trips of its wave, its own
+//              units of work, and the wave's trips that ran both branches
+//   101..164   the wave runs a branch only when at least (variant - 100) lanes
+//              want it or it is the majority's (1 = always: the production loop
+//              with each branch loading its own record)
+//   200 + d    as 101 with the LDS stack sized for d entries: fewer workgroups
+//              per CU, i.e. what occupancy is worth (d >= the tree's depth)
 
 #include "kernels.hpp"
 #include "traverse.hpp"
@@ -212,6 +219,7 @@ __global__ __launch_bounds__(kBlock) void k_variant_nested_loops(const DeviceTre
 
 // Experiment: a trip runs a branch only if at least `threshold` lanes want it
 // or it is the majority's; the minority's lanes wait for company.
+// Variants 100 and up (see the list at the top).
 __global__ __launch_bounds__(kBlock) void k_variant_threshold(const DeviceTree tree, const float *rays, uint64_t n,
                                                               rta_hit *hits, const int depth, const int threshold)
 {

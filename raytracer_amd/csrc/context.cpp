@@ -71,6 +71,9 @@ struct rta_context {
 	// scene
 	bool have_scene = false;
 	DeviceBuffer pairs, prims, shade_prims, materials, lights, ref_nodes;
+	DeviceBuffer soa_nodes;      // variant 5 only, made from `pairs` on first use
+	uint32_t n_pairs = 0;
+	bool have_soa = false;
 	uint32_t root_ref = 0;
 	bool tame = false;           // box coordinates allow the reciprocal slab test (traverse.hpp)
 	int stack_depth = 1;
@@ -448,6 +451,8 @@ int rta_upload_scene(rta_context *ctx, const rta_scene_desc *desc)
 		return rc;
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // the staging vectors die with this call
 	ctx->root_ref = f.root;
+	ctx->n_pairs = (uint32_t)(f.pairs.size() / 4);
+	ctx->have_soa = false;
 	ctx->tame = f.tame;
 	ctx->stack_depth = f.depth;
 	ctx->n_prims = desc->n_prims;
@@ -507,11 +512,16 @@ int rta_debug_trace_variant(rta_context *ctx, int variant, const float *rays, in
 		return rta_trace_closest(ctx, rays, n, hits, mem);
 	if (!ctx->have_scene)
 		return ctx->fail(RTA_E_NO_SCENE, "no scene uploaded");
-	if (variant < 1 || (variant > 4 && variant < 100) || variant > 360 || (variant >= 200 && variant - 200 < ctx->stack_depth) || n <= 0 || !rays || !hits || mem != RTA_MEM_DEVICE)
+	if (variant < 1 || (variant > 5 && variant < 100) || variant > 360 || (variant >= 200 && variant - 200 < ctx->stack_depth) || n <= 0 || !rays || !hits || mem != RTA_MEM_DEVICE)
 		return ctx->fail(RTA_E_INVALID, "variants 1..4 take device-resident ray batches");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
-	launch_variant(ctx->stream, variant, tree_of(ctx), ctx->ref_nodes.as<const float4>(), rays, (uint64_t)n, hits,
-	               ctx->stack_depth);
+	if (variant == 5 && !ctx->have_soa) {
+		HIP_TRY(ctx, ctx->soa_nodes.reserve((size_t)ctx->n_pairs * 14 * 4));
+		launch_pairs_to_soa(ctx->stream, ctx->pairs.as<const float4>(), ctx->n_pairs, ctx->soa_nodes.as<float>());
+		ctx->have_soa = true;
+	}
+	launch_variant(ctx->stream, variant, tree_of(ctx), ctx->ref_nodes.as<const float4>(), ctx->soa_nodes.as<const float>(),
+	               ctx->n_pairs, rays, (uint64_t)n, hits, ctx->stack_depth);
 	HIP_TRY(ctx, hipGetLastError());
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	return RTA_OK;

@@ -91,7 +91,8 @@ void launch_batch_occluded(hipStream_t s, const TreeRef &tree, const float *rays
 void launch_arith(hipStream_t s, int op, const float *x, const float *y, float *out, uint64_t n);
 // variants.hip: closest hit with one design decision changed (1 private stack,
 // 2 division-based box test, 3 reference node layout); measurement only
-void launch_variant(hipStream_t s, int variant, const TreeRef &tree, const float4 *reference_nodes, const float *rays,
-                    uint64_t n, rta_hit *hits, int depth);
+void launch_variant(hipStream_t s, int variant, const TreeRef &tree, const float4 *reference_nodes, const float *soa_nodes,
+                    uint32_t n_pairs, const float *rays, uint64_t n, rta_hit *hits, int depth);
+void launch_pairs_to_soa(hipStream_t s, const float4 *pairs, uint32_t n_pairs, float *soa);
 
 }  // namespace rta

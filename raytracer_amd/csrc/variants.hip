@@ -12,6 +12,10 @@
 //   4  two nested loops per ray (walk inner nodes down to a leaf, then test all
 //      of the leaf's primitives) instead of one loop whose every trip is one
 //      node visit or one primitive test
+//   5  struct-of-arrays nodes: the 14 words of a pair record in 14 arrays, so
+//      that a visit issues 14 four-byte gathers instead of four 16-byte loads
+//      from one 64-byte line (one ray per lane: neighbouring lanes are at
+//      unrelated nodes, so the arrays buy no coalescing)
 //   100        not a variant but a census: per ray the trips of its wave, its own
 //              units of work, and the wave's trips that ran both branches
 //   101..164   the wave runs a branch only when at least (variant - 100) lanes
@@ -219,6 +223,47 @@ __global__ __launch_bounds__(kBlock) void k_variant_nested_loops(const DeviceTre
 
 // Experiment: a trip runs a branch only if at least `threshold` lanes want it
 // or it is the majority's; the minority's lanes wait for company.
+// pairs (64-byte records) -> 14 arrays of n_pairs words each
+__global__ __launch_bounds__(kBlock) void k_pairs_to_soa(const float4 *pairs, uint32_t n_pairs, float *soa)
+{
+	const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+	if (p >= n_pairs)
+		return;
+	const float *rec = (const float *)(pairs + 4 * (size_t)p);
+	for (int f = 0; f < 14; f++)
+		soa[(size_t)f * n_pairs + p] = rec[f];
+}
+
+__global__ __launch_bounds__(kBlock) void k_variant_soa_nodes(const DeviceTree tree, const float *soa, uint32_t n_pairs,
+                                                              const float *rays, uint64_t n, rta_hit *hits,
+                                                              const int depth)
+{
+	extern __shared__ uint32_t lds_stack[];
+	uint32_t *stack = lds_stack + threadIdx.x;
+	const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+	if (i >= n)
+		return;
+	const float *r = rays + i * 6;
+	Traversal<false, false> tr;
+	WorkCount wc = {0, 0, 0};
+	tr.start(tree, Ray{mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5])}, FLT_MAX);
+	while (__ballot(tr.more)) {
+		if (!tr.more)
+			continue;
+		if (tr.at_prim()) {
+			tr.test_prim(tree, stack, wc);
+		} else {
+			float w[14];
+			for (int f = 0; f < 14; f++)
+				w[f] = soa[(size_t)f * n_pairs + tr.node];
+			tr.inner_unit(make_float4(w[0], w[1], w[2], w[3]), make_float4(w[4], w[5], w[6], w[7]),
+			              make_float4(w[8], w[9], w[10], w[11]), make_float4(w[12], w[13], 0.f, 0.f), stack, depth, wc);
+		}
+	}
+	const HitRec h = tr.result();
+	hits[i] = rta_hit{h.prim, h.t, h.u, h.v};
+}
+
 // Variants 100 and up (see the list at the top).
 __global__ __launch_bounds__(kBlock) void k_variant_threshold(const DeviceTree tree, const float *rays, uint64_t n,
                                                               rta_hit *hits, const int depth, const int threshold)
@@ -259,8 +304,13 @@ __global__ __launch_bounds__(kBlock) void k_variant_threshold(const DeviceTree t
 
 }  // namespace
 
-void launch_variant(hipStream_t s, int variant, const TreeRef &tree, const float4 *reference_nodes, const float *rays,
-                    uint64_t n, rta_hit *hits, int depth)
+void launch_pairs_to_soa(hipStream_t s, const float4 *pairs, uint32_t n_pairs, float *soa)
+{
+	hipLaunchKernelGGL(k_pairs_to_soa, dim3((n_pairs + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pairs, n_pairs, soa);
+}
+
+void launch_variant(hipStream_t s, int variant, const TreeRef &tree, const float4 *reference_nodes, const float *soa_nodes,
+                    uint32_t n_pairs, const float *rays, uint64_t n, rta_hit *hits, int depth)
 {
 	const unsigned blocks = (unsigned)((n + kBlock - 1) / kBlock);
 	const size_t lds = (size_t)depth * kBlock * sizeof(uint32_t);
@@ -284,6 +334,10 @@ void launch_variant(hipStream_t s, int variant, const TreeRef &tree, const float
 		break;
 	case 4:
 		hipLaunchKernelGGL(k_variant_nested_loops, dim3(blocks), dim3(kBlock), lds, s, tree, rays, n, hits, depth);
+		break;
+	case 5:
+		hipLaunchKernelGGL(k_variant_soa_nodes, dim3(blocks), dim3(kBlock), lds, s, tree, soa_nodes, n_pairs, rays, n, hits,
+		                   depth);
 		break;
 	default:
 		hipLaunchKernelGGL(k_variant_reference_nodes, dim3(blocks), dim3(kBlock), lds, s, tree, reference_nodes, rays, n,

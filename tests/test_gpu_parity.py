@@ -322,7 +322,7 @@ def test_design_variants_return_the_same_bits(gpu):
     want = gpu.trace_closest(rr)
     dev = torch.device("cuda", 0)
     rt = torch.from_numpy(np.ascontiguousarray(rr)).to(dev)
-    for variant in (0, 1, 2, 3, 4):
+    for variant in (0, 1, 2, 3, 4, 5, 101, 124):
         ht = torch.zeros((rr.shape[0], 4), dtype=torch.float32, device=dev)
         gpu.trace_variant_device(variant, rt.data_ptr(), rr.shape[0], ht.data_ptr())
         got = ht.cpu().numpy()

@@ -21,7 +21,8 @@ NAMES = {0: "production (64 B pair records, LDS stack, reciprocal box test, one 
          1: "stack in private memory",
          2: "division-based box test",
          3: "reference 32 B nodes + node-number stack",
-         4: "nested loops (inner nodes to a leaf, then the whole leaf)"}
+         4: "nested loops (inner nodes to a leaf, then the whole leaf)",
+         5: "struct-of-arrays nodes (14 four-byte gathers per visit)"}
 
 
 def main():
@@ -49,7 +50,7 @@ def main():
         rt = torch.from_numpy(np.ascontiguousarray(rr)).to(dev)
         n = rr.shape[0]
         base = None
-        for variant in [int(v) for v in os.environ.get("VARIANTS", "0,1,2,3,4").split(",")]:
+        for variant in [int(v) for v in os.environ.get("VARIANTS", "0,1,2,3,4,5").split(",")]:
             ht = torch.zeros((n, 4), dtype=torch.float32, device=dev)
             try:
                 ctx.trace_variant_device(variant, rt.data_ptr(), n, ht.data_ptr())

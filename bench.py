@@ -213,6 +213,11 @@ def main():
             if tj.get("workload") == w["label"] and tj.get("kernel") == "k_intersect":
                 line["roofline"]["traffic"] = tj["hbm_bytes_per_ray"] * rays_per_launch
                 line["roofline"]["traffic_source"] = "profiles/traffic.json (%s)" % tj.get("tag")
+                if tj.get("valu_wave_instructions_per_ray"):
+                    # second axis: share of the vector-ALU issue slots the whole pipeline uses
+                    # (profiled wave instructions per ray x 4 cycles, 1024 SIMDs at 2.4 GHz)
+                    line["roofline"]["valu_busy_frac"] = (tj["valu_wave_instructions_per_ray"] * 4.0 * rays_all /
+                                                          elapsed / world / (1024 * 2.4e9))
         if args.count_work and tot["rays"]:
             line["roofline"]["measured_bytes_per_ray"] = (64.0 * tot["inner_visits"] + 36.0 * tot["tri_tests"] +
                                                           16.0 * tot["sph_tests"]) / (tot["rays"] +

@@ -81,6 +81,7 @@ struct rta_context {
 
 	// wavefront workspace
 	DeviceBuffer ray0, ray1, hit, thr, col, rng, acc, meta, q_ray, shadow, partial, pixels, frame, bgr, counters;
+	DeviceBuffer part_weights, part_order;
 	DeviceBuffer io_a, io_b, io_c;       // staging for host-pointer calls
 	Counters *host_counters = nullptr;    // pinned, kMaxGroups entries
 
@@ -691,6 +692,9 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	const uint32_t pass_blocks = std::min<uint64_t>(n_blocks, (uint64_t)groups_per_pass * blocks_per_group);
 	HIP_TRY(ctx, ctx->partial.reserve(std::max<size_t>((size_t)pass_blocks * n_pad, 1) * 16));
 	HIP_TRY(ctx, ctx->pixels.reserve(std::max<size_t>(n_pad, 1) * 4));
+	const uint32_t n_parts = n_tiles * lane_blocks;
+	HIP_TRY(ctx, ctx->part_weights.reserve(std::max<size_t>(n_parts, 1) * 4));
+	HIP_TRY(ctx, ctx->part_order.reserve(std::max<size_t>(n_parts, 1) * 4));
 
 	const bool to_device = p->out_mem == RTA_MEM_DEVICE;
 	float *d_frame = nullptr;
@@ -727,6 +731,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	base.n_blocks = n_blocks;
 	base.run_blocks = run_blocks;
 	base.lane_blocks = lane_blocks;
+	base.part_order = ctx->part_order.as<const uint32_t>();
 	base.spp = spp;
 	base.sps = sps;
 	base.width = (uint32_t)p->width;
@@ -763,13 +768,15 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	const bool lights = ctx->n_lights > 0;
 	hipStream_t s = ctx->stream;
 
-	hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+	hipEvent_t ev_begin = nullptr, ev_mid = nullptr, ev_end = nullptr;
 	HIP_TRY(ctx, hipEventCreate(&ev_begin));
+	HIP_TRY(ctx, hipEventCreate(&ev_mid));
 	HIP_TRY(ctx, hipEventCreate(&ev_end));
 	std::vector<hipEvent_t> ev_pool;        // begin/end pairs around timed launches, then the per-group end marks
 	std::vector<int> ev_kind;               // 0 intersect, 1 shadow
 	auto cleanup = [&]() {
 		(void)hipEventDestroy(ev_begin);
+		(void)hipEventDestroy(ev_mid);
 		(void)hipEventDestroy(ev_end);
 		for (hipEvent_t e : ev_pool)
 			(void)hipEventDestroy(e);
@@ -786,8 +793,27 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	if (n_pad)
 		HIP_TRY_R(hipMemcpyAsync(ctx->pixels.ptr, px.data(), (size_t)n_pad * 4, hipMemcpyHostToDevice, s));
 	HIP_TRY_R(hipEventRecord(ev_begin, s));
+	// Heaviest parts of the image first: one ray per pixel tells which parts see
+	// geometry, a counting sort (stable, so equal parts keep their order) makes the
+	// list the waves draw their items from.
+	if (n_parts) {
+		std::vector<uint32_t> weight(n_parts), order(n_parts);
+		launch_part_weights(s, ga[0], ctx->part_weights.as<uint32_t>(), ctx->stack_depth);
+		HIP_TRY_R(hipMemcpyAsync(weight.data(), ctx->part_weights.ptr, (size_t)n_parts * 4, hipMemcpyDeviceToHost, s));
+		HIP_TRY_R(hipStreamSynchronize(s));
+		uint32_t start[66] = {0};
+		for (uint32_t w : weight)
+			start[64 - std::min(w, 64u) + 1]++;
+		for (int k = 1; k < 66; k++)
+			start[k] += start[k - 1];
+		for (uint32_t k = 0; k < n_parts; k++)
+			order[start[64 - std::min(weight[k], 64u)]++] = k;
+		HIP_TRY_R(hipMemcpyAsync(ctx->part_order.ptr, order.data(), (size_t)n_parts * 4, hipMemcpyHostToDevice, s));
+		HIP_TRY_R(hipStreamSynchronize(s));       // `order` dies here
+	}
+	HIP_TRY_R(hipEventRecord(ev_mid, s));
 	for (int g = 1; g < groups; g++)
-		HIP_TRY_R(hipStreamWaitEvent(gs[g], ev_begin, 0));
+		HIP_TRY_R(hipStreamWaitEvent(gs[g], ev_mid, 0));
 	// The wavefront loop.  Progress lives on the device; the host reads it back
 	// every `poll` steps only to notice the end (steps past the end find every
 	// slot retired and do nothing).  The groups' steps are issued round-robin on
@@ -827,6 +853,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 			ga[g].first_group = g0;
 			ga[g].first_block = first_block;
 			ga[g].n_items = n_tiles * lane_blocks * (g1 - g0);
+			ga[g].pass_groups = g1 - g0;
 			launch_init_slots(gs[g], ga[g], group_slots);
 		}
 		bool done = false;

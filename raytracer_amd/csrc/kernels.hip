@@ -348,8 +348,10 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 		if (got < a.n_items) {
 			// item -> (tile, part of the tile, group of block runs); the wave's lanes
 			// cover the part's 64 / lane_blocks pixels x lane_blocks block runs
-			const uint32_t rest = got / a.n_tiles, tile = got - rest * a.n_tiles;
-			const uint32_t part = rest % a.lane_blocks, group = a.first_group + rest / a.lane_blocks;
+			// items come heaviest part first (part_order), all groups of a part in a row
+			const uint32_t k = got / a.pass_groups, group = a.first_group + (got - k * a.pass_groups);
+			const uint32_t which = a.part_order[k];
+			const uint32_t tile = which / a.lane_blocks, part = which - tile * a.lane_blocks;
 			const uint32_t part_pixels = 64 / a.lane_blocks;
 			const uint32_t padded = tile * 64 + part * part_pixels + lane % part_pixels;
 			const uint32_t first = (group * a.lane_blocks + lane / part_pixels) * a.run_blocks;
@@ -528,6 +530,40 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 		count_flush(a.cnt, wc);
 }
 
+// ------------------------------------------------------------------ item weights
+
+// How expensive will the parts of the tiles be?  One ray through the centre of
+// every pixel; a part's weight is the number of its pixels that see geometry.
+// Heavier parts are handed out first, so that the render does not end on a few
+// waves that drew a long item late.  Only the schedule depends on this, never a
+// result, so the ray needs none of the reference's arithmetic.
+__global__ __launch_bounds__(kBlock) void k_part_weights(const RenderArgs a, uint32_t *weights, const int depth)
+{
+	extern __shared__ uint32_t lds_stack[];
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;      // index in the padded pixel list
+	const int32_t pixel = i < a.n_pad ? a.pixels[i] : -1;
+	bool seen = false;
+	if (pixel >= 0) {
+		const uint32_t pu = (uint32_t)pixel % a.width, pv = (uint32_t)pixel / a.width;
+		const V3 o = mk(a.cam.origin[0], a.cam.origin[1], a.cam.origin[2]);
+		const V3 ul = mk(a.cam.upper_left[0], a.cam.upper_left[1], a.cam.upper_left[2]);
+		const V3 du = mk(a.cam.du[0], a.cam.du[1], a.cam.du[2]);
+		const V3 dv = mk(a.cam.dv[0], a.cam.dv[1], a.cam.dv[2]);
+		const V3 target = (ul + du * ((float)pu + .5f)) + dv * ((float)pv + .5f);
+		HitRec h;
+		WorkCount wc = {0, 0, 0};
+		traverse_dyn<true, false>(a.tree, Ray{o, unit(target - o)}, FLT_MAX, lds_stack + threadIdx.x, depth, h, wc);
+		seen = h.prim >= 0;
+	}
+	// a wave covers one tile; its lanes split into lane_blocks parts of 64 / lane_blocks pixels
+	const uint32_t part_pixels = 64 / a.lane_blocks, lane = threadIdx.x & 63;
+	const unsigned long long votes = __ballot(seen);
+	if (i < a.n_pad && lane % part_pixels == 0) {
+		const unsigned long long mask = part_pixels == 64 ? ~0ull : ((1ull << part_pixels) - 1) << lane;
+		weights[(i / 64) * a.lane_blocks + lane / part_pixels] = (uint32_t)__popcll(votes & mask);
+	}
+}
+
 // ------------------------------------------------------------------ finish
 
 // Pixel sum = block sums added in block order from zero (`resume`: from the sum
@@ -693,6 +729,11 @@ static inline size_t stack_bytes(int depth) { return (size_t)depth * kBlock * si
 void launch_init_slots(hipStream_t s, const RenderArgs &a, uint32_t n_slots)
 {
 	hipLaunchKernelGGL(k_init_slots, dim3(blocks_for(n_slots)), dim3(kBlock), 0, s, a, n_slots);
+}
+
+void launch_part_weights(hipStream_t s, const RenderArgs &a, uint32_t *weights, int depth)
+{
+	hipLaunchKernelGGL(k_part_weights, dim3(blocks_for(a.n_pad)), dim3(kBlock), stack_bytes(depth), s, a, weights, depth);
 }
 
 void launch_advance(hipStream_t s, const RenderArgs &a, int par)

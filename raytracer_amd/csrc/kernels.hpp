@@ -68,6 +68,8 @@ struct RenderArgs {
 	uint32_t lane_blocks;          // block runs a wave works on side by side (1, 2, 4 or 8), on 64 / lane_blocks pixels
 	uint32_t n_items;              // of the pass: n_tiles * lane_blocks * its groups of lane_blocks block runs
 	uint32_t first_group, first_block;     // where the pass starts
+	uint32_t pass_groups;          // groups of lane_blocks block runs in the pass
+	const uint32_t *part_order;    // tile * lane_blocks + part, heaviest first (see k_part_weights)
 	uint32_t spp, sps;
 	uint32_t width;
 	uint32_t seed;
@@ -77,6 +79,7 @@ struct RenderArgs {
 };
 
 void launch_init_slots(hipStream_t s, const RenderArgs &a, uint32_t n_slots);
+void launch_part_weights(hipStream_t s, const RenderArgs &a, uint32_t *weights, int depth);
 void launch_advance(hipStream_t s, const RenderArgs &a, int par);
 void launch_intersect(hipStream_t s, const RenderArgs &a, int par, int depth, bool count);
 void launch_shadow(hipStream_t s, const RenderArgs &a, uint32_t bound, int depth, bool count);

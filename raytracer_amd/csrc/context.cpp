@@ -739,8 +739,8 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	base.max_bounces = p->max_bounces > 0 ? p->max_bounces : 10;
 	memcpy(base.sky, p->sky, sizeof base.sky);
 	base.cam = *camera;
-	base.rays_per_lane = 4;       // measured on dragon.txt: 2 and 8 lose 2-4 %
-	base.refill_at = 16;          // likewise 8 and 32
+	base.rays_per_lane = 8;       // measured on dragon.txt: 4 and 12 lose 1-2 %
+	base.refill_at = 24;          // likewise 16 (8 loses 3 %)
 
 	// one RenderArgs and one stream per slot group
 	std::vector<RenderArgs> ga((size_t)groups, base);

@@ -663,7 +663,11 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	const uint32_t n_slots = group_slots * (uint32_t)groups;
 	if (items64 + n_slots >= 0xffffffffull || (uint64_t)n_blocks * n_pad >= 0xffffffffull)
 		return ctx->fail(RTA_E_LIMIT, "tiles x sample blocks exceeds 2^32; raise samples_per_stream");
-	const uint32_t n_items = (uint32_t)items64;
+	// A wave draws new streams when all its lanes are waiting.  Drawing earlier
+	// (measured at 4..32 waiting lanes) fills idle lanes but loses more than it
+	// gains: the wave's camera rays stop coming from one part of the image at one
+	// sample index.
+	const uint32_t grab_at = 64;
 
 	// workspace (grow-only, reused across calls)
 	const size_t S = n_slots;
@@ -723,7 +727,6 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	base.lights = ctx->lights.as<const float4>();
 	base.n_lights = ctx->n_lights;
 	base.n_slots = group_slots;
-	base.next_item = &ctx->counters.as<Counters>()[0].next_item;
 	base.partial = ctx->partial.as<float4>();
 	base.pixels = ctx->pixels.as<const int32_t>();
 	base.n_tiles = n_tiles;
@@ -839,7 +842,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		launch();
 		return hipEventRecord(e1, st_);
 	};
-	for (uint32_t g0 = 0; g0 < n_groups && n_items; g0 += groups_per_pass) {
+	for (uint32_t g0 = 0; g0 < n_groups && n_parts; g0 += groups_per_pass) {
 		const uint32_t g1 = std::min(n_groups, g0 + groups_per_pass);
 		const uint32_t first_block = g0 * blocks_per_group;
 		const uint32_t end_block = std::min<uint64_t>(n_blocks, (uint64_t)g1 * blocks_per_group);
@@ -850,10 +853,16 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		HIP_TRY_R(hipMemcpyAsync(ctx->counters.ptr, ctx->host_counters, sizeof(Counters) * kMaxGroups, hipMemcpyHostToDevice, s));
 		HIP_TRY_R(hipStreamSynchronize(s));       // host_counters is reused for read-back below; the groups are idle
 		for (int g = 0; g < groups; g++) {
-			ga[g].first_group = g0;
+			// the sorted parts are dealt round-robin to the slot groups; a part's
+			// streams are its pixels x the block runs of the pass
+			const uint32_t parts_here = (n_parts + (uint32_t)groups - 1 - (uint32_t)g) / (uint32_t)groups;
 			ga[g].first_block = first_block;
-			ga[g].n_items = n_tiles * lane_blocks * (g1 - g0);
-			ga[g].pass_groups = g1 - g0;
+			ga[g].end_block = end_block;
+			ga[g].group = (uint32_t)g;
+			ga[g].n_groups = (uint32_t)groups;
+			ga[g].streams_per_part = (64 / lane_blocks) * ((end_block - first_block + run_blocks - 1) / run_blocks);
+			ga[g].n_streams = parts_here * ga[g].streams_per_part;
+			ga[g].grab_at = grab_at;
 			launch_init_slots(gs[g], ga[g], group_slots);
 		}
 		bool done = false;

@@ -339,39 +339,52 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 		A.w = __uint_as_float(done);
 	}
 
-	// the whole wave is through: draw the next item
-	if (__ballot(state == kWaiting) == ~0ull) {
-		uint32_t got = 0;
+	// Lanes without a stream draw the next ones of the group's list as soon as
+	// grab_at of them are waiting, or at once when nothing else is left to do in
+	// the wave.  The list is ordered: parts of the image heaviest first
+	// (part_order, dealt round-robin to the slot groups), within a part its
+	// 64 / lane_blocks pixels for the first block run, then for the second, ...
+	// so that the streams a wave draws together are neighbours in the image.
+	const unsigned long long waiting = __ballot(state == kWaiting);
+	const uint32_t n_wait = (uint32_t)__popcll(waiting);
+	if (n_wait && (n_wait >= a.grab_at || __ballot(state != kWaiting && state != kRetired) == 0)) {
+		uint32_t base = 0;
 		if (lane == 0)
-			got = atomicAdd(a.next_item, 1u);
-		got = __shfl(got, 0);
-		if (got < a.n_items) {
-			// item -> (tile, part of the tile, group of block runs); the wave's lanes
-			// cover the part's 64 / lane_blocks pixels x lane_blocks block runs
-			// items come heaviest part first (part_order), all groups of a part in a row
-			const uint32_t k = got / a.pass_groups, group = a.first_group + (got - k * a.pass_groups);
-			const uint32_t which = a.part_order[k];
-			const uint32_t tile = which / a.lane_blocks, part = which - tile * a.lane_blocks;
-			const uint32_t part_pixels = 64 / a.lane_blocks;
-			const uint32_t padded = tile * 64 + part * part_pixels + lane % part_pixels;
-			const uint32_t first = (group * a.lane_blocks + lane / part_pixels) * a.run_blocks;
-			const int32_t pixel = a.pixels[padded];
-			if (pixel >= 0 && first < a.n_blocks) {
-				M.x = (uint32_t)pixel;
-				M.y = first;
-				M.z = first + a.run_blocks < a.n_blocks ? first + a.run_blocks : a.n_blocks;
-				M.w = padded;
-				a.meta[slot] = M;
-				rng = stream_seed(a.seed, M.x, M.y);
-				A = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
-				need_ray = true;
+			base = atomicAdd(&a.cnt->next_item, n_wait);
+		base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+		const uint32_t got = base < a.n_streams ? (a.n_streams - base < n_wait ? a.n_streams - base : n_wait) : 0u;
+		const uint32_t rank =
+		    __builtin_amdgcn_mbcnt_hi((uint32_t)(waiting >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)waiting, 0u));
+		if (state == kWaiting) {
+			if (rank < got) {
+				const uint32_t stream = base + rank;
+				const uint32_t k = stream / a.streams_per_part, within = stream - k * a.streams_per_part;
+				const uint32_t which = a.part_order[k * a.n_groups + a.group];
+				const uint32_t tile = which / a.lane_blocks, part = which - tile * a.lane_blocks;
+				const uint32_t part_pixels = 64 / a.lane_blocks;
+				const uint32_t run = within / part_pixels, px = within - run * part_pixels;
+				const uint32_t padded = tile * 64 + part * part_pixels + px;
+				const uint32_t first = a.first_block + run * a.run_blocks;
+				const int32_t pixel = a.pixels[padded];
+				if (pixel >= 0) {          // (a tile that leaves the frame has streams without a pixel)
+					M.x = (uint32_t)pixel;
+					M.y = first;
+					M.z = first + a.run_blocks < a.end_block ? first + a.run_blocks : a.end_block;
+					M.w = padded;
+					a.meta[slot] = M;
+					rng = stream_seed(a.seed, M.x, M.y);
+					A = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
+					need_ray = true;
+					state = 0;             // (the camera ray written below carries bounce 0)
+				}
+			} else {
+				state = kRetired;          // the list is dry
 			}
-		} else {
-			state = kRetired;
-			if (lane == 0)
-				atomicSub(&a.cnt->live, 1u);
 		}
 	}
+	// every lane retired (not so on entry): the wave is through
+	if (__ballot(state != kRetired) == 0 && lane == 0)
+		atomicSub(&a.cnt->live, 1u);
 
 	if (need_ray) {
 		a.acc[slot] = A;

@@ -16,7 +16,7 @@ constexpr uint32_t kRayKinds = 3;     // camera rays, bounce rays, rays needing 
 // Device-resident progress and statistics of one slot group (see RenderArgs).
 struct Counters {
 	uint32_t n_shadow;       // pending occlusion queries
-	uint32_t next_item;      // next (tile, block run) to hand to a wave; only group 0's is used
+	uint32_t next_item;      // streams of the group's list already handed out
 	uint32_t live;           // waves that still have or may get work
 	uint32_t pad;
 	unsigned long long rays, shadow_rays;
@@ -59,16 +59,17 @@ struct RenderArgs {
 	// occlusion queue, 3 per entry: (origin, limit) (direction, slot) (radiance, -)
 	float4 *shadow;
 	Counters *cnt;                 // this group's
-	uint32_t *next_item;           // shared by all groups
 
 	float4 *partial;               // block sums of the pass, [block - first_block][padded pixel]
 	const int32_t *pixels;         // this shard's pixels, 64 per tile, -1 where a tile leaves the frame
 	uint32_t n_tiles, n_pad;       // n_pad = 64 * n_tiles
-	uint32_t n_blocks, run_blocks; // sample blocks per pixel; consecutive blocks a lane works through per item
-	uint32_t lane_blocks;          // block runs a wave works on side by side (1, 2, 4 or 8), on 64 / lane_blocks pixels
-	uint32_t n_items;              // of the pass: n_tiles * lane_blocks * its groups of lane_blocks block runs
-	uint32_t first_group, first_block;     // where the pass starts
-	uint32_t pass_groups;          // groups of lane_blocks block runs in the pass
+	uint32_t n_blocks, run_blocks; // sample blocks per pixel; consecutive blocks a lane works through as one stream
+	uint32_t lane_blocks;          // a tile is cut into lane_blocks parts of 64 / lane_blocks pixels (1, 2, 4 or 8)
+	uint32_t first_block, end_block;       // the pass renders blocks [first_block, end_block)
+	uint32_t group, n_groups;      // this slot group and how many there are
+	uint32_t streams_per_part;     // pixels of a part x block runs of the pass
+	uint32_t n_streams;            // in this group's list (Counters::next_item counts them out)
+	uint32_t grab_at;              // waiting lanes that make a wave draw new streams
 	const uint32_t *part_order;    // tile * lane_blocks + part, heaviest first (see k_part_weights)
 	uint32_t spp, sps;
 	uint32_t width;

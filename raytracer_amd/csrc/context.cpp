@@ -76,6 +76,8 @@ struct rta_context {
 	bool have_soa = false;
 	uint32_t root_ref = 0;
 	bool tame = false;           // box coordinates allow the reciprocal slab test (traverse.hpp)
+	bool box_known = false;      // `box` is the box around the root's two children
+	float box[6] = {0, 0, 0, 0, 0, 0};
 	int stack_depth = 1;
 	int32_t n_prims = 0, n_lights = 0;
 
@@ -187,6 +189,8 @@ struct Flattened {
 	uint32_t root = 0;
 	int depth = 0;
 	bool tame = true;
+	bool box_known = false;            // `box`: lo xyz, hi xyz around the root's two children
+	float box[6] = {0, 0, 0, 0, 0, 0};
 };
 
 inline float as_float(uint32_t u)
@@ -285,6 +289,16 @@ std::string flatten(const rta_scene_desc &d, Flattened &out)
 		if (!(m == 0.f || (m >= 0x1p-78f && m <= 0x1p40f)))
 			out.tame = false;
 	}
+	// The box around the root's children (the root's own box is never tested,
+	// src/main.cpp:332-350, and a caller-made tree need not have a tight one).
+	if (out.tame && d.node_count[0] == 0) {
+		const float *a = d.node_bounds + (size_t)d.node_index[0] * 6, *b = a + 6;
+		for (int k = 0; k < 3; k++) {
+			out.box[k] = std::min(a[k], b[k]);
+			out.box[3 + k] = std::max(a[3 + k], b[3 + k]);
+		}
+		out.box_known = true;
+	}
 	out.pairs.resize(std::max<size_t>(inner_order.size(), 1) * 4, make_float4(0, 0, 0, 0));
 	for (size_t p = 0; p < inner_order.size(); p++) {
 		int32_t l = d.node_index[inner_order[p]], r = l + 1;
@@ -354,7 +368,15 @@ int upload_vec(rta_context *ctx, DeviceBuffer &buf, const std::vector<T> &v)
 
 TreeRef tree_of(const rta_context *ctx)
 {
-	return TreeRef{ctx->pairs.as<const float4>(), ctx->prims.as<const float4>(), ctx->root_ref, ctx->tame ? 1u : 0u};
+	TreeRef t;
+	t.pairs = ctx->pairs.as<const float4>();
+	t.prims = ctx->prims.as<const float4>();
+	t.root = ctx->root_ref;
+	t.tame = ctx->tame ? 1u : 0u;
+	t.box_known = ctx->box_known ? 1u : 0u;
+	memcpy(t.box_lo, ctx->box, 12);
+	memcpy(t.box_hi, ctx->box + 3, 12);
+	return t;
 }
 
 // Owned pixels in walk order: tiles row-major, pixels row-major inside a tile.
@@ -453,6 +475,8 @@ int rta_upload_scene(rta_context *ctx, const rta_scene_desc *desc)
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // the staging vectors die with this call
 	ctx->root_ref = f.root;
 	ctx->n_pairs = (uint32_t)(f.pairs.size() / 4);
+	ctx->box_known = f.box_known;
+	memcpy(ctx->box, f.box, sizeof ctx->box);
 	ctx->have_soa = false;
 	ctx->tame = f.tame;
 	ctx->stack_depth = f.depth;
@@ -735,6 +759,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	base.run_blocks = run_blocks;
 	base.lane_blocks = lane_blocks;
 	base.part_order = ctx->part_order.as<const uint32_t>();
+	base.fast_trips = 64;         // measured on dragon.txt: 4 loses 4 %, 32 and 128 are within 1 %
 	base.spp = spp;
 	base.sps = sps;
 	base.width = (uint32_t)p->width;

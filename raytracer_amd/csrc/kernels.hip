@@ -105,8 +105,8 @@ RTA_DEV void ray_queue_push(const RenderArgs &a, int par, int kind, bool pred, u
 
 // ------------------------------------------------------------------ advance
 
-// One camera sample of pixel `pixel` (src/main.cpp:663-687) written into `slot`.
-RTA_DEV Ray camera_ray(const RenderArgs &a, uint32_t slot, uint32_t pixel, uint32_t &rng)
+// One camera sample of pixel `pixel` (src/main.cpp:663-687).
+RTA_DEV Ray camera_ray(const RenderArgs &a, uint32_t pixel, uint32_t &rng)
 {
 	const uint32_t pu = pixel % a.width, pv = pixel / a.width;
 	const V3 cam_o = mk(a.cam.origin[0], a.cam.origin[1], a.cam.origin[2]);
@@ -140,9 +140,25 @@ RTA_DEV Ray camera_ray(const RenderArgs &a, uint32_t slot, uint32_t pixel, uint3
 	const V3 dv = mk(a.cam.dv[0], a.cam.dv[1], a.cam.dv[2]);
 	const V3 target = (ul + du * ((float)pu + .5f + ju)) + dv * ((float)pv + .5f + jv);
 	const V3 dir = unit(target - origin);
-	a.ray0[slot] = make_float4(origin.x, origin.y, origin.z, dir.x);
-	a.ray1[slot] = make_float4(dir.y, dir.z, 1.f, __uint_as_float(0u));     // bsdf_pdf = 1, bounce 0
 	return Ray{origin, dir};
+}
+
+// True only if the ray provably misses the box around the whole scene, and with
+// it every node: a child's box lies inside it and the slab quotients are
+// monotonic in the planes, so in the reference's own arithmetic both children of
+// the root then fail their box tests (src/main.cpp:381-401) and NearestHit
+// returns "no hit" without testing a primitive.  Decided from products with an
+// approximate reciprocal (1 ulp), which are within a factor 1 +- 2^-21 of the
+// quotients and have their sign (tame rays and scenes), with a margin of 2^-18.
+RTA_DEV bool misses_the_scene(const TreeRef &tree, const Ray &r)
+{
+	if (!tree.box_known || !ray_is_tame(r))
+		return false;
+	const V3 rcp = mk(__builtin_amdgcn_rcpf(r.d.x), __builtin_amdgcn_rcpf(r.d.y), __builtin_amdgcn_rcpf(r.d.z));
+	float t_in, t_out;
+	approx_box(mk(tree.box_lo[0], tree.box_lo[1], tree.box_lo[2]), mk(tree.box_hi[0], tree.box_hi[1], tree.box_hi[2]), r,
+	           rcp, t_in, t_out);
+	return t_out < 0.f || t_out * (1.f + 0x1p-18f) < t_in;
 }
 
 // Everything between two traversals of a slot, in one pass over the slot state:
@@ -309,90 +325,130 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 		ended = true;
 	}
 
+	// Retire, draw new streams, generate - and again, for as long as some lane's
+	// new camera ray provably misses the whole scene: such a sample is over at
+	// once (src/main.cpp:511-514 with throughput 1 and radiance 0), so streams over
+	// empty sky run through many samples per pass without a queue entry, a
+	// traversal or a word of slot state moved.  Lanes whose ray must be traced keep
+	// it and wait for the loop to end.
 	uint4 M = make_uint4(0u, 0u, 0u, 0u);     // pixel, current block, end of the block run, index in the padded pixel list
 	float4 A = make_float4(0.f, 0.f, 0.f, 0.f);     // block sum, samples finished in the block
-	bool need_ray = false;
-	if (ended) {
-		// the finished sample joins its block sum (src/main.cpp:689)
-		M = a.meta[slot];
-		A = a.acc[slot];
-		uint32_t done = __float_as_uint(A.w) + 1;
-		A.x += color.x;
-		A.y += color.y;
-		A.z += color.z;
-		const uint32_t first = M.y * a.sps;
-		const uint32_t len = a.spp - first < a.sps ? a.spp - first : a.sps;
-		need_ray = true;
-		if (done >= len) {
-			a.partial[(size_t)(M.y - a.first_block) * a.n_pad + M.w] = make_float4(A.x, A.y, A.z, 0.f);
-			A = make_float4(0.f, 0.f, 0.f, 0.f);
-			done = 0;
-			M.y++;
-			if (M.y >= M.z) {
-				state = kWaiting;
-				need_ray = false;
-			} else {
-				rng = stream_seed(a.seed, M.x, M.y);
-				a.meta[slot] = M;
+	bool need_ray = false, have_ray = false, in_registers = false, meta_changed = false;
+	uint32_t answered_here = 0;
+	for (uint32_t trip = 0;; trip++) {
+		if (ended) {
+			// the finished sample joins its block sum (src/main.cpp:689)
+			if (!in_registers) {
+				M = a.meta[slot];
+				A = a.acc[slot];
+				in_registers = true;
 			}
-		}
-		A.w = __uint_as_float(done);
-	}
-
-	// Lanes without a stream draw the next ones of the group's list as soon as
-	// grab_at of them are waiting, or at once when nothing else is left to do in
-	// the wave.  The list is ordered: parts of the image heaviest first
-	// (part_order, dealt round-robin to the slot groups), within a part its
-	// 64 / lane_blocks pixels for the first block run, then for the second, ...
-	// so that the streams a wave draws together are neighbours in the image.
-	const unsigned long long waiting = __ballot(state == kWaiting);
-	const uint32_t n_wait = (uint32_t)__popcll(waiting);
-	if (n_wait && (n_wait >= a.grab_at || __ballot(state != kWaiting && state != kRetired) == 0)) {
-		uint32_t base = 0;
-		if (lane == 0)
-			base = atomicAdd(&a.cnt->next_item, n_wait);
-		base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-		const uint32_t got = base < a.n_streams ? (a.n_streams - base < n_wait ? a.n_streams - base : n_wait) : 0u;
-		const uint32_t rank =
-		    __builtin_amdgcn_mbcnt_hi((uint32_t)(waiting >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)waiting, 0u));
-		if (state == kWaiting) {
-			if (rank < got) {
-				const uint32_t stream = base + rank;
-				const uint32_t k = stream / a.streams_per_part, within = stream - k * a.streams_per_part;
-				const uint32_t which = a.part_order[k * a.n_groups + a.group];
-				const uint32_t tile = which / a.lane_blocks, part = which - tile * a.lane_blocks;
-				const uint32_t part_pixels = 64 / a.lane_blocks;
-				const uint32_t run = within / part_pixels, px = within - run * part_pixels;
-				const uint32_t padded = tile * 64 + part * part_pixels + px;
-				const uint32_t first = a.first_block + run * a.run_blocks;
-				const int32_t pixel = a.pixels[padded];
-				if (pixel >= 0) {          // (a tile that leaves the frame has streams without a pixel)
-					M.x = (uint32_t)pixel;
-					M.y = first;
-					M.z = first + a.run_blocks < a.end_block ? first + a.run_blocks : a.end_block;
-					M.w = padded;
-					a.meta[slot] = M;
+			uint32_t done = __float_as_uint(A.w) + 1;
+			A.x += color.x;
+			A.y += color.y;
+			A.z += color.z;
+			const uint32_t first = M.y * a.sps;
+			const uint32_t len = a.spp - first < a.sps ? a.spp - first : a.sps;
+			need_ray = true;
+			if (done >= len) {
+				a.partial[(size_t)(M.y - a.first_block) * a.n_pad + M.w] = make_float4(A.x, A.y, A.z, 0.f);
+				A = make_float4(0.f, 0.f, 0.f, 0.f);
+				done = 0;
+				M.y++;
+				meta_changed = true;
+				if (M.y >= M.z) {
+					state = kWaiting;
+					need_ray = false;
+				} else {
 					rng = stream_seed(a.seed, M.x, M.y);
-					A = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
-					need_ray = true;
-					state = 0;             // (the camera ray written below carries bounce 0)
 				}
-			} else {
-				state = kRetired;          // the list is dry
+			}
+			A.w = __uint_as_float(done);
+			ended = false;
+		}
+
+		// Lanes without a stream draw the next ones of the group's list as soon as
+		// grab_at of them are waiting, or at once when nothing else is left to do in
+		// the wave.  The list is ordered: parts of the image heaviest first
+		// (part_order, dealt round-robin to the slot groups), within a part its
+		// 64 / lane_blocks pixels for the first block run, then for the second, ...
+		// so that the streams a wave draws together are neighbours in the image.
+		const unsigned long long waiting = __ballot(state == kWaiting);
+		const uint32_t n_wait = (uint32_t)__popcll(waiting);
+		if (n_wait && (n_wait >= a.grab_at || __ballot(state != kWaiting && state != kRetired) == 0)) {
+			uint32_t base = 0;
+			if (lane == 0)
+				base = atomicAdd(&a.cnt->next_item, n_wait);
+			base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+			const uint32_t got = base < a.n_streams ? (a.n_streams - base < n_wait ? a.n_streams - base : n_wait) : 0u;
+			const uint32_t rank =
+			    __builtin_amdgcn_mbcnt_hi((uint32_t)(waiting >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)waiting, 0u));
+			if (state == kWaiting) {
+				if (rank < got) {
+					const uint32_t stream = base + rank;
+					const uint32_t k = stream / a.streams_per_part, within = stream - k * a.streams_per_part;
+					const uint32_t which = a.part_order[k * a.n_groups + a.group];
+					const uint32_t tile = which / a.lane_blocks, part = which - tile * a.lane_blocks;
+					const uint32_t part_pixels = 64 / a.lane_blocks;
+					const uint32_t run = within / part_pixels, px = within - run * part_pixels;
+					const uint32_t padded = tile * 64 + part * part_pixels + px;
+					const uint32_t first = a.first_block + run * a.run_blocks;
+					const int32_t pixel = a.pixels[padded];
+					if (pixel >= 0) {          // (a tile that leaves the frame has streams without a pixel)
+						M.x = (uint32_t)pixel;
+						M.y = first;
+						M.z = first + a.run_blocks < a.end_block ? first + a.run_blocks : a.end_block;
+						M.w = padded;
+						in_registers = true;
+						meta_changed = true;
+						rng = stream_seed(a.seed, M.x, M.y);
+						A = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
+						need_ray = true;
+						state = 0;             // (a camera ray carries bounce 0)
+					}
+				} else {
+					state = kRetired;          // the list is dry
+				}
 			}
 		}
+		// every lane retired (not so on entry): the wave is through
+		if (__ballot(state != kRetired) == 0) {
+			if (lane == 0)
+				atomicSub(&a.cnt->live, 1u);
+			break;
+		}
+
+		if (need_ray && !have_ray) {
+			next_ray = camera_ray(a, M.x, rng);
+			have_ray = true;
+		}
+		const bool answered = need_ray && trip < a.fast_trips && misses_the_scene(a.tree, next_ray);
+		if (__ballot(answered) == 0)
+			break;
+		if (answered) {
+			color = mk(0, 0, 0) + mk(1, 1, 1) * mk(a.sky[0], a.sky[1], a.sky[2]);
+			ended = true;
+			need_ray = false;
+			have_ray = false;
+			answered_here++;
+		}
 	}
-	// every lane retired (not so on entry): the wave is through
-	if (__ballot(state != kRetired) == 0 && lane == 0)
-		atomicSub(&a.cnt->live, 1u);
 
 	if (need_ray) {
 		a.acc[slot] = A;
-		next_ray = camera_ray(a, slot, M.x, rng);
 		a.rng[slot] = rng;
+		if (meta_changed)
+			a.meta[slot] = M;
+		a.ray0[slot] = make_float4(next_ray.o.x, next_ray.o.y, next_ray.o.z, next_ray.d.x);
+		a.ray1[slot] = make_float4(next_ray.d.y, next_ray.d.z, 1.f, __uint_as_float(0u));     // bsdf_pdf = 1, bounce 0
 	} else if (state >= kWaiting && state != __float_as_uint(r1.w)) {
 		a.ray1[slot] = make_float4(r1.x, r1.y, r1.z, __uint_as_float(state));
 	}
+	// rays answered above count like traced ones (each stands for one NearestHit call)
+	for (int m = 32; m >= 1; m >>= 1)
+		answered_here += __shfl_xor(answered_here, m);
+	if (answered_here && lane == 0)
+		atomicAdd(&a.cnt->rays, (unsigned long long)answered_here);
 
 	// camera rays are coherent (a wave's rays cross one tile), bounce rays are not:
 	// they are queued apart so that a traversal wave holds rays of one kind

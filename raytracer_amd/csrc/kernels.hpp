@@ -30,6 +30,8 @@ struct TreeRef {
 	const float4 *prims;
 	uint32_t root;
 	uint32_t tame;           // every box coordinate is 0 or within [2^-78, 2^40] in magnitude
+	uint32_t box_known;      // box_lo/box_hi hold the box around the root's two children (tame trees with an inner root)
+	float box_lo[3], box_hi[3];
 };
 
 // Everything a wavefront kernel needs, passed by value.  The slot pool is cut
@@ -70,6 +72,7 @@ struct RenderArgs {
 	uint32_t streams_per_part;     // pixels of a part x block runs of the pass
 	uint32_t n_streams;            // in this group's list (Counters::next_item counts them out)
 	uint32_t grab_at;              // waiting lanes that make a wave draw new streams
+	uint32_t fast_trips;           // samples a lane may finish per pass without tracing (rays that miss the whole scene)
 	const uint32_t *part_order;    // tile * lane_blocks + part, heaviest first (see k_part_weights)
 	uint32_t spp, sps;
 	uint32_t width;

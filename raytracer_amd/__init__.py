@@ -66,7 +66,8 @@ class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("steps", C.c_uint64),
                 ("inner_visits", C.c_uint64), ("tri_tests", C.c_uint64), ("sph_tests", C.c_uint64),
                 ("gpu_ms", C.c_double), ("intersect_ms", C.c_double), ("shadow_ms", C.c_double),
-                ("intersect_launches", C.c_uint64), ("shadow_launches", C.c_uint64)]
+                ("intersect_launches", C.c_uint64), ("shadow_launches", C.c_uint64),
+                ("early_rays", C.c_uint64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

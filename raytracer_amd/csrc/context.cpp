@@ -917,7 +917,8 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		}
 		for (int g = 0; g < groups; g++) {
 			const Counters &c = ctx->host_counters[g];
-			st.rays += c.rays;
+			st.rays += c.rays + c.early;
+			st.early_rays += c.early;
 			st.shadow_rays += c.shadow_rays;
 			st.inner_visits += c.inner;
 			st.tri_tests += c.tri;

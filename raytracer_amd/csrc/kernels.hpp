@@ -23,6 +23,7 @@ struct Counters {
 	uint32_t n_ray[2 * kRayKinds * kShards];     // closest-hit queue lengths, [step parity][kind][shard]
 	uint32_t head[2 * kShards];                  // bounce-ray entries already drawn by traversal waves, [step parity][shard]
 	unsigned long long inner, tri, sph;     // RTA_RENDER_COUNT_WORK only
+	unsigned long long early;               // closest-hit queries answered where the ray was generated
 };
 
 struct TreeRef {

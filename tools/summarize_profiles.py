@@ -86,11 +86,12 @@ def main():
                    "write_bytes_per_ray": ki["WRITE_SIZE"] * 1024 / rays,
                    "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs; KiB -> bytes; "
                              "read side doubled (gfx950 FETCH_SIZE counts 64 B per 128 B request)"}
-        # vector-ALU work of the whole pipeline per traced ray (wave instructions; one
+        # vector-ALU work of the whole pipeline per ray (wave instructions; one
         # takes 4 cycles of one SIMD), for the bench line's second roofline axis
         sq_bench = bench_line(os.path.join(src, "pmc_sq.log"))
         if sq_bench:
-            sq_rays = sq_bench["roofline"]["rays_per_launch"] * sq_bench["roofline"]["launches"]
+            # every query of the run, those answered without a traversal included
+            sq_rays = sq_bench["value"] * 1e6 * sq_bench["ms_per_step"] * 1e-3 * sq_bench["steps"]
             traffic["valu_wave_instructions_per_ray"] = sum(
                 v.get("SQ_INSTS_VALU", 0.0) for v in summary["kernels"].values()) / sq_rays
         with open(os.path.join(dst, "traffic.json"), "w") as f:

@@ -105,34 +105,45 @@ RTA_DEV void ray_queue_push(const RenderArgs &a, int par, int kind, bool pred, u
 
 // ------------------------------------------------------------------ advance
 
-// One camera sample of pixel `pixel` (src/main.cpp:663-687).
-RTA_DEV Ray camera_ray(const RenderArgs &a, uint32_t pixel, uint32_t &rng)
+// The random numbers of one camera sample (src/main.cpp:665-683), in the
+// reference's order: the lens point, then the two of the pixel filter.
+struct CameraDraws {
+	float lens_x, lens_y, u1, u2;
+};
+
+RTA_DEV CameraDraws camera_draws(const RenderArgs &a, uint32_t &rng)
 {
-	const uint32_t pu = pixel % a.width, pv = pixel / a.width;
+	CameraDraws d = {0.f, 0.f, 0.f, 0.f};
+	if (a.cam.defocus_angle > 0) {
+		// src/main.cpp:105-113,665-669; the accept test is x*y < 1 as written there
+		for (;;) {
+			d.lens_x = rng_float(rng) * 2 - 1;
+			d.lens_y = rng_float(rng) * 2 - 1;
+			if (d.lens_x * d.lens_y < 1)
+				break;
+		}
+	}
+	do {
+		d.u1 = rng_float(rng);
+	} while (d.u1 == 0);
+	d.u2 = rng_float(rng);
+	return d;
+}
+
+// One camera sample of pixel (pu, pv) from its random numbers (src/main.cpp:663-687).
+RTA_DEV Ray camera_ray(const RenderArgs &a, uint32_t pu, uint32_t pv, const CameraDraws &d)
+{
 	const V3 cam_o = mk(a.cam.origin[0], a.cam.origin[1], a.cam.origin[2]);
 	V3 origin = cam_o;
 	if (a.cam.defocus_angle > 0) {
-		// src/main.cpp:105-113,665-669; the accept test is x*y < 1 as written there
-		float lx, ly;
-		for (;;) {
-			lx = rng_float(rng) * 2 - 1;
-			ly = rng_float(rng) * 2 - 1;
-			if (lx * ly < 1)
-				break;
-		}
 		const V3 lu = mk(a.cam.lens_u[0], a.cam.lens_u[1], a.cam.lens_u[2]);
 		const V3 lv = mk(a.cam.lens_v[0], a.cam.lens_v[1], a.cam.lens_v[2]);
-		origin = (cam_o + lu * lx) + lv * ly;
+		origin = (cam_o + lu * d.lens_x) + lv * d.lens_y;
 	}
 	// Gaussian pixel filter by Box-Muller, sigma = 0.5 px (src/main.cpp:674-683)
-	float u1;
-	do {
-		u1 = rng_float(rng);
-	} while (u1 == 0);
-	const float u2 = rng_float(rng);
-	const float radius = .5f * __builtin_sqrtf(-2 * pm_logf(u1));
+	const float radius = .5f * __builtin_sqrtf(-2 * pm_logf(d.u1));
 	float sj, cj;
-	pm_sincosf(2 * kPiF * u2, &sj, &cj);
+	pm_sincosf(2 * kPiF * d.u2, &sj, &cj);
 	const float ju = radius * cj;
 	const float jv = radius * sj;
 	const V3 ul = mk(a.cam.upper_left[0], a.cam.upper_left[1], a.cam.upper_left[2]);
@@ -141,6 +152,27 @@ RTA_DEV Ray camera_ray(const RenderArgs &a, uint32_t pixel, uint32_t &rng)
 	const V3 target = (ul + du * ((float)pu + .5f + ju)) + dv * ((float)pv + .5f + jv);
 	const V3 dir = unit(target - origin);
 	return Ray{origin, dir};
+}
+
+// The pixel filter moves a sample by radius = .5 sqrt(-2 ln u1) pixels from the
+// pixel's centre.  If the centre is further than that from the rectangle the
+// scene's box projects into (box_x0..box_y1, margin included), the sample's ray
+// misses the box whatever its angle u2 - and that is decided by u1 >= the value
+// returned here, exp(-2 distance^2), without logarithm, sine, root or quotient.
+// 2 means "never" (u1 < 1).  Rounded up, so that rounding only ever sends a
+// sample the long way.
+RTA_DEV float sky_threshold(const RenderArgs &a, uint32_t pu, uint32_t pv)
+{
+	if (!a.box_seen)
+		return 2.f;
+	const float cx = (float)pu + .5f, cy = (float)pv + .5f;
+	const float dx = greater(greater(a.box_x0 - cx, cx - a.box_x1), 0.f);
+	const float dy = greater(greater(a.box_y0 - cy, cy - a.box_y1), 0.f);
+	const float d2 = dx * dx + dy * dy;
+	if (!(d2 > 0.f))
+		return 2.f;
+	// __expf is good to a few ulp; the factor covers that and the roundings above
+	return __expf(-2.f * d2) * (1.f + 0x1p-10f) + 0x1p-120f;
 }
 
 // True only if the ray provably misses the box around the whole scene, and with
@@ -335,6 +367,8 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 	float4 A = make_float4(0.f, 0.f, 0.f, 0.f);     // block sum, samples finished in the block
 	bool need_ray = false, have_ray = false, in_registers = false, meta_changed = false;
 	uint32_t answered_here = 0;
+	uint32_t sky_pixel = 0xffffffffu, sky_pu = 0, sky_pv = 0;     // the pixel sky_u1 belongs to
+	float sky_u1 = 2.f;
 	for (uint32_t trip = 0;; trip++) {
 		if (ended) {
 			// the finished sample joins its block sum (src/main.cpp:689)
@@ -418,11 +452,23 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 			break;
 		}
 
+		bool answered = false;
 		if (need_ray && !have_ray) {
-			next_ray = camera_ray(a, M.x, rng);
-			have_ray = true;
+			if (sky_pixel != M.x) {
+				sky_pixel = M.x;
+				sky_pu = M.x % a.width;
+				sky_pv = M.x / a.width;
+				sky_u1 = sky_threshold(a, sky_pu, sky_pv);
+			}
+			const CameraDraws draws = camera_draws(a, rng);
+			if (trip < a.fast_trips && draws.u1 >= sky_u1) {
+				answered = true;      // too close to the pixel's centre to reach the scene's box
+			} else {
+				next_ray = camera_ray(a, sky_pu, sky_pv, draws);
+				have_ray = true;
+				answered = trip < a.fast_trips && misses_the_scene(a.tree, next_ray);
+			}
 		}
-		const bool answered = need_ray && trip < a.fast_trips && misses_the_scene(a.tree, next_ray);
 		if (__ballot(answered) == 0)
 			break;
 		if (answered) {

@@ -73,6 +73,11 @@ struct RenderArgs {
 	uint32_t streams_per_part;     // pixels of a part x block runs of the pass
 	uint32_t n_streams;            // in this group's list (Counters::next_item counts them out)
 	uint32_t grab_at;              // waiting lanes that make a wave draw new streams
+	// Pinhole cameras looking at a tame tree: the scene's box projects into the
+	// rectangle [box_x0, box_x1] x [box_y0, box_y1] of the image plane (pixel units,
+	// a safety margin included); box_seen = 0 when no such rectangle is known.
+	uint32_t box_seen;
+	float box_x0, box_x1, box_y0, box_y1;
 	uint32_t fast_trips;           // samples a lane may finish per pass without tracing (rays that miss the whole scene)
 	const uint32_t *part_order;    // tile * lane_blocks + part, heaviest first (see k_part_weights)
 	uint32_t spp, sps;

@@ -251,6 +251,40 @@ def test_features_unused_by_the_shipped_scenes(gpu):
     assert np.array_equal(bgr, want_bgr)
 
 
+def _box_mesh(lo, hi):
+    """12 triangles of the axis-parallel box lo..hi as a triangle_mesh block."""
+    (x0, y0, z0), (x1, y1, z1) = lo, hi
+    c = [(x0, y0, z0), (x1, y0, z0), (x1, y1, z0), (x0, y1, z0), (x0, y0, z1), (x1, y0, z1), (x1, y1, z1), (x0, y1, z1)]
+    quads = [(0, 1, 2, 3), (4, 7, 6, 5), (0, 4, 5, 1), (1, 5, 6, 2), (2, 6, 7, 3), (3, 7, 4, 0)]
+    rows = []
+    for a, b, cc, d in quads:
+        for tri in ((a, b, cc), (a, cc, d)):
+            rows.append(" ".join(f"{v:g}" for i in tri for v in c[i]))
+    return "triangle_mesh {\n\tvertices [\n\t\t" + "\n\t\t".join(rows) + "\n\t]\n}\n"
+
+
+@pytest.mark.parametrize("camera,look_at", [("[-3 0 0.1]", "[0 0 0.1]"), ("[-2.5 1.3 0.9]", "[0 0.1 0]")])
+def test_samples_answered_from_the_pixel_filter_radius(gpu, camera, look_at):
+    """Camera samples whose pixel-filter radius cannot reach the projection of
+    the scene's box are given the sky without a ray.  A box-shaped mesh fills
+    its own bounding box, so its outline IS the projection's (seen along an
+    axis: all four edges), and every pixel around the outline mixes samples
+    decided either way: all must agree with the checker's full computation."""
+    text = ("render {\n\tcamera %s\n\tlook_at %s\n\tsamples 96\n\twidth 44\n\theight 40\n"
+            "\tsky_box_color [.5 .6 1]\n}\n\nmaterial {\n\tcolor [0.8 0.3 0.2]\n\tior 1.5\n\troughness 1\n\tmetallic 0\n}\n\n"
+            % (camera, look_at)) + _box_mesh((-0.5, -0.62, -0.41), (0.5, 0.57, 0.63))
+    osc = orc.Scene.parse(text).build_bvh()
+    psc = rta.Scene.parse(text).build_bvh()
+    gpu.upload(psc)
+    want_bgr, want_acc, want_cn = osc.render(orc.RNG_STREAM, orc.MATH_PM, seed=77, samples_per_stream=8)
+    bgr, acc, st = gpu.render_scene(psc, seed=77, samples_per_stream=8)
+    assert st["rays"] == want_cn["rays"]
+    assert 0 < st["early_rays"] < st["rays"]          # some samples took the short way, not all
+    same = bits(acc) == bits(want_acc)
+    assert same.all(), f"{(~same).any(axis=2).sum()} pixels differ in radiance bits"
+    assert np.array_equal(bgr, want_bgr)
+
+
 def test_triangle_soup_indices_bit_exact(gpu):
     """The intersect-only workload at test size: 200 k random triangles, a
     coherent pinhole grid and incoherent rays; every index and t must match."""

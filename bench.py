@@ -35,15 +35,19 @@ import raytracer_amd as rta  # noqa: E402
 # boxes), 36 B per triangle test, 16 B per sphere test, 40 B ray in + hit out,
 # with the reference traversal's own visit counts per workload.
 WORKLOADS = {
-    "dragon1080p": dict(scene="dragon.txt", width=1920, height=1080, spp=1024, bytes_per_ray=691.0,
+    "dragon1080p": dict(scene="dragon.txt", width=1920, height=1080, spp=1024, bytes_per_ray=691.0, early_bytes=156.0,
                         cpu_spp=256, label="scenes/dragon.txt 1920x1080 1024spp"),
-    "cornell1080p": dict(scene="cornell_box.txt", width=1920, height=1080, spp=256, bytes_per_ray=764.0,
+    "cornell1080p": dict(scene="cornell_box.txt", width=1920, height=1080, spp=256, bytes_per_ray=764.0, early_bytes=104.0,
                          cpu_spp=64, label="scenes/cornell_box.txt 1920x1080 256spp"),
-    "dragon4k": dict(scene="dragon.txt", width=3840, height=2160, spp=4096, bytes_per_ray=691.0,
+    "dragon4k": dict(scene="dragon.txt", width=3840, height=2160, spp=4096, bytes_per_ray=691.0, early_bytes=156.0,
                      cpu_spp=64, label="scenes/dragon.txt 3840x2160 4096spp"),
 }
+# early_bytes: what the reference traversal moves for a closest-hit query that the GPU path answers
+# without a traversal (a camera ray that misses every leaf's box): 40 B ray and hit + 64 B per node
+# visit.  One visit on cornell (its root has two leaves); 1.8 on average on dragon = the reference's
+# 651 B of node and triangle reads per query less the 567 B per query that `--count-work` counts on
+# the device for the rays that are traced, over the 72 % of the queries that are not.
 HBM_PEAK_GBS = 8000.0
-EARLY_BYTES = 104.0
 
 
 def cpu_baseline(w, threads):
@@ -178,11 +182,11 @@ def main():
         launches = max(tot["intersect_launches"], 1)
         avg_ms = tot["intersect_ms"] / launches
         # bytes_per_ray averages over every closest-hit query of the workload; a query answered
-        # where its ray is generated (it misses the box around the scene) stands for one node
-        # visit (64 B) + ray and hit (40 B) of that total and never reaches this kernel
+        # where its ray is generated never reaches this kernel, and its share of that total
+        # (early_bytes) is not credited to it
         traced = tot["rays"] - tot["early_rays"]
         rays_per_launch = traced / launches
-        kernel_bytes = tot["rays"] * w["bytes_per_ray"] - tot["early_rays"] * EARLY_BYTES
+        kernel_bytes = tot["rays"] * w["bytes_per_ray"] - tot["early_rays"] * w["early_bytes"]
         traced_bytes_per_ray = kernel_bytes / max(traced, 1)
         achieved = kernel_bytes / launches / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         line = {

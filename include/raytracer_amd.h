@@ -196,8 +196,9 @@ typedef struct {
 	double gpu_ms;                          /* whole render on the context's stream */
 	double intersect_ms, shadow_ms;         /* RTA_RENDER_TIME_KERNELS only: summed launch durations */
 	uint64_t intersect_launches, shadow_launches;
-	uint64_t early_rays;                    /* of `rays`: camera rays that miss the box around the scene, answered
-	                                         * by the kernel that generates them and never queued for traversal */
+	uint64_t early_rays;                    /* of `rays`: camera rays that provably miss every leaf's box (the
+	                                         * reference's NearestHit would test no primitive), answered where
+	                                         * they are generated and never queued for traversal */
 } rta_stats;
 
 /* The render loop.  Replaces src/main.cpp:657-714 (row loop, per-sample ray

@@ -84,6 +84,7 @@ struct rta_context {
 	// wavefront workspace
 	DeviceBuffer ray0, ray1, hit, thr, col, rng, acc, meta, q_ray, shadow, partial, pixels, frame, bgr, counters;
 	DeviceBuffer part_weights, part_order;
+	DeviceBuffer cover, sky_map;         // see k_sky_map
 	DeviceBuffer io_a, io_b, io_c;       // staging for host-pointer calls
 	Counters *host_counters = nullptr;    // pinned, kMaxGroups entries
 
@@ -633,62 +634,50 @@ int rta_resolve(rta_context *ctx, const float *accum, int32_t width, int32_t hei
 	return RTA_OK;
 }
 
-// Where on the image plane can the scene be seen?  For a pinhole camera every
-// ray starts at the camera's origin, so a sample whose point on the image plane
-// lies outside the projection of the scene's box misses the box.  The eight
-// corners are projected in binary64 and the rectangle around them is widened by
-// kBoxMargin pixels - orders of magnitude more than the binary32 roundings of
-// the sample's target point and of the reference's slab test can move either.
-// No rectangle (box_seen = 0) if the lens has a size, if the box is unknown or
-// if a corner is not well in front of the camera.
-static void project_scene_box(RenderArgs &a)
+// Can samples be decided on the image plane (see k_sky_map)?  Only for a pinhole
+// camera (every ray starts at the camera's origin) that sees all of the scene's
+// box well in front of it, with perpendicular image axes.  The margin by which
+// the projected boxes are widened is 0.05 pixels + 1e-5 radians: orders of
+// magnitude more than the binary32 roundings of a sample's point on the image
+// plane, of its ray and of the reference's slab test can move either.
+static bool projection_of(const rta_camera &cam, const TreeRef &tree, Projection &pr)
 {
-	constexpr double kBoxMargin = 0.05;
-	a.box_seen = 0;
-	if (!a.tree.box_known || a.cam.defocus_angle > 0)
-		return;
-	const float *o = a.cam.origin, *ul = a.cam.upper_left, *du = a.cam.du, *dv = a.cam.dv;
-	const double n[3] = {(double)du[1] * dv[2] - (double)du[2] * dv[1], (double)du[2] * dv[0] - (double)du[0] * dv[2],
-	                     (double)du[0] * dv[1] - (double)du[1] * dv[0]};
-	double h = 0, du2 = 0, dv2 = 0, dudv = 0;
+	if (!tree.box_known || cam.defocus_angle > 0)
+		return false;
 	for (int k = 0; k < 3; k++) {
-		h += ((double)ul[k] - o[k]) * n[k];
-		du2 += (double)du[k] * du[k];
-		dv2 += (double)dv[k] * dv[k];
-		dudv += (double)du[k] * dv[k];
+		pr.o[k] = cam.origin[k];
+		pr.ul[k] = cam.upper_left[k];
+		pr.du[k] = cam.du[k];
+		pr.dv[k] = cam.dv[k];
 	}
-	// the plane's axes must be perpendicular (they are for rta_camera_from_settings)
-	if (!(du2 > 0) || !(dv2 > 0) || !(fabs(dudv) <= 1e-6 * sqrt(du2 * dv2)) || !(fabs(h) > 0))
-		return;
-	double x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+	pr.n[0] = pr.du[1] * pr.dv[2] - pr.du[2] * pr.dv[1];
+	pr.n[1] = pr.du[2] * pr.dv[0] - pr.du[0] * pr.dv[2];
+	pr.n[2] = pr.du[0] * pr.dv[1] - pr.du[1] * pr.dv[0];
+	double dudv = 0, n2 = 0;
+	pr.h = pr.du2 = pr.dv2 = 0;
+	for (int k = 0; k < 3; k++) {
+		pr.h += (pr.ul[k] - pr.o[k]) * pr.n[k];
+		pr.du2 += pr.du[k] * pr.du[k];
+		pr.dv2 += pr.dv[k] * pr.dv[k];
+		dudv += pr.du[k] * pr.dv[k];
+		n2 += pr.n[k] * pr.n[k];
+	}
+	if (!(pr.du2 > 0) || !(pr.dv2 > 0) || !(fabs(dudv) <= 1e-6 * sqrt(pr.du2 * pr.dv2)) || !(fabs(pr.h) > 0) || !(n2 > 0))
+		return false;
 	for (int c = 0; c < 8; c++) {
-		double w[3], depth = 0;
-		for (int k = 0; k < 3; k++) {
-			w[k] = (double)((c >> k) & 1 ? a.tree.box_hi[k] : a.tree.box_lo[k]) - o[k];
-			depth += w[k] * n[k];
-		}
-		const double scale = h / depth;      // the corner is seen at o + w * scale
+		double depth = 0;
+		for (int k = 0; k < 3; k++)
+			depth += ((double)((c >> k) & 1 ? tree.box_hi[k] : tree.box_lo[k]) - pr.o[k]) * pr.n[k];
+		const double scale = pr.h / depth;
 		if (!(scale > 0) || !(scale < 1e6))
-			return;
-		double x = 0, y = 0;
-		for (int k = 0; k < 3; k++) {
-			const double p = (double)o[k] + w[k] * scale - ul[k];
-			x += p * du[k];
-			y += p * dv[k];
-		}
-		x /= du2;
-		y /= dv2;
-		x0 = std::min(x0, x), x1 = std::max(x1, x);
-		y0 = std::min(y0, y), y1 = std::max(y1, y);
+			return false;
 	}
-	if (!(std::isfinite(x0) && std::isfinite(x1) && std::isfinite(y0) && std::isfinite(y1)))
-		return;
-	a.box_x0 = (float)(x0 - kBoxMargin) - 1e-3f * fabsf((float)x0);
-	a.box_x1 = (float)(x1 + kBoxMargin) + 1e-3f * fabsf((float)x1);
-	a.box_y0 = (float)(y0 - kBoxMargin) - 1e-3f * fabsf((float)y0);
-	a.box_y1 = (float)(y1 + kBoxMargin) + 1e-3f * fabsf((float)y1);
-	a.box_seen = 1;
+	// one pixel is sqrt(min(du2, dv2)) wide on a plane |h| / |n| away
+	const double pixel_angle = sqrt(std::min(pr.du2, pr.dv2)) / (fabs(pr.h) / sqrt(n2));
+	pr.margin = 0.05 + 1e-5 / pixel_angle;
+	return std::isfinite(pr.margin) && pr.margin < 1.0;
 }
+
 
 int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_params *p, float *accum, uint8_t *bgr,
                rta_stats *stats)
@@ -824,7 +813,13 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	base.max_bounces = p->max_bounces > 0 ? p->max_bounces : 10;
 	memcpy(base.sky, p->sky, sizeof base.sky);
 	base.cam = *camera;
-	project_scene_box(base);
+	Projection projection;
+	const bool with_sky_map = n_owned > 0 && projection_of(*camera, base.tree, projection);
+	if (with_sky_map) {
+		HIP_TRY(ctx, ctx->cover.reserve(((size_t)p->width + 2 * kSkyBorder) * ((size_t)p->height + 2 * kSkyBorder)));
+		HIP_TRY(ctx, ctx->sky_map.reserve(frame_px * 4));
+		base.sky_map = ctx->sky_map.as<const float>();
+	}
 	base.rays_per_lane = 8;       // measured on dragon.txt: 4 and 12 lose 1-2 %
 	base.refill_at = 24;          // likewise 16 (8 loses 3 %)
 
@@ -879,6 +874,9 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	if (n_pad)
 		HIP_TRY_R(hipMemcpyAsync(ctx->pixels.ptr, px.data(), (size_t)n_pad * 4, hipMemcpyHostToDevice, s));
 	HIP_TRY_R(hipEventRecord(ev_begin, s));
+	if (with_sky_map)
+		launch_sky_map(s, base.tree, ctx->n_pairs, projection, (uint32_t)p->width, (uint32_t)p->height,
+		               ctx->cover.as<uint8_t>(), ctx->sky_map.as<float>());
 	// Heaviest parts of the image first: one ray per pixel tells which parts see
 	// geometry, a counting sort (stable, so equal parts keep their order) makes the
 	// list the waves draw their items from.

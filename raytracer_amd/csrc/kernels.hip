@@ -154,27 +154,6 @@ RTA_DEV Ray camera_ray(const RenderArgs &a, uint32_t pu, uint32_t pv, const Came
 	return Ray{origin, dir};
 }
 
-// The pixel filter moves a sample by radius = .5 sqrt(-2 ln u1) pixels from the
-// pixel's centre.  If the centre is further than that from the rectangle the
-// scene's box projects into (box_x0..box_y1, margin included), the sample's ray
-// misses the box whatever its angle u2 - and that is decided by u1 >= the value
-// returned here, exp(-2 distance^2), without logarithm, sine, root or quotient.
-// 2 means "never" (u1 < 1).  Rounded up, so that rounding only ever sends a
-// sample the long way.
-RTA_DEV float sky_threshold(const RenderArgs &a, uint32_t pu, uint32_t pv)
-{
-	if (!a.box_seen)
-		return 2.f;
-	const float cx = (float)pu + .5f, cy = (float)pv + .5f;
-	const float dx = greater(greater(a.box_x0 - cx, cx - a.box_x1), 0.f);
-	const float dy = greater(greater(a.box_y0 - cy, cy - a.box_y1), 0.f);
-	const float d2 = dx * dx + dy * dy;
-	if (!(d2 > 0.f))
-		return 2.f;
-	// __expf is good to a few ulp; the factor covers that and the roundings above
-	return __expf(-2.f * d2) * (1.f + 0x1p-10f) + 0x1p-120f;
-}
-
 // True only if the ray provably misses the box around the whole scene, and with
 // it every node: a child's box lies inside it and the slab quotients are
 // monotonic in the planes, so in the reference's own arithmetic both children of
@@ -458,7 +437,7 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 				sky_pixel = M.x;
 				sky_pu = M.x % a.width;
 				sky_pv = M.x / a.width;
-				sky_u1 = sky_threshold(a, sky_pu, sky_pv);
+				sky_u1 = a.sky_map ? a.sky_map[M.x] : 2.f;
 			}
 			const CameraDraws draws = camera_draws(a, rng);
 			if (trip < a.fast_trips && draws.u1 >= sky_u1) {
@@ -679,6 +658,99 @@ __global__ __launch_bounds__(kBlock) void k_part_weights(const RenderArgs a, uin
 	}
 }
 
+// ------------------------------------------------------------------ sky map
+
+// Which samples need no ray at all?  A primitive is only tested once the ray has
+// passed the box test of its leaf (src/main.cpp:381-401), so a ray that misses
+// every leaf's box - by far more than binary32 rounding can move the slab
+// quotients - ends in the sky.  For a pinhole camera all rays of the image start
+// at one point, and a box is then missed by every ray whose point on the image
+// plane lies outside the rectangle around the box's eight projected corners.
+//
+// k_cover_leaves marks the pixel-sized cells of the image plane (the frame and
+// kSkyBorder cells around it) that some leaf's rectangle, widened by the margin,
+// touches; one wave per (pair record, child).
+__global__ __launch_bounds__(kBlock) void k_cover_leaves(const TreeRef tree, const uint32_t n_pairs, const Projection pr,
+                                                        const int map_w, const int map_h, uint8_t *cover)
+{
+	const uint32_t item = blockIdx.x * (kBlock / 64) + threadIdx.x / 64, lane = threadIdx.x & 63;
+	if (item >= 2 * n_pairs)
+		return;
+	const float4 *rec = tree.pairs + 4 * (size_t)(item >> 1);
+	const float4 q3 = rec[3];
+	const uint32_t ref = (item & 1) ? __float_as_uint(q3.y) : __float_as_uint(q3.x);
+	if (!(ref & kLeafBit))
+		return;
+	const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+	const float lo[3] = {(item & 1) ? q1.z : q0.x, (item & 1) ? q1.w : q0.y, (item & 1) ? q2.x : q0.z};
+	const float hi[3] = {(item & 1) ? q2.y : q0.w, (item & 1) ? q2.z : q1.x, (item & 1) ? q2.w : q1.y};
+	double x0 = 1e9, x1 = -1e9, y0 = 1e9, y1 = -1e9;
+	bool everywhere = false;      // a corner that is not safely in front of the camera: no statement about this box
+	for (int c = 0; c < 8; c++) {
+		double w[3], depth = 0;
+		for (int k = 0; k < 3; k++) {
+			w[k] = (double)(((c >> k) & 1) ? hi[k] : lo[k]) - pr.o[k];
+			depth += w[k] * pr.n[k];
+		}
+		const double scale = pr.h / depth;
+		if (!(scale > 0) || !(scale < 1e6))
+			everywhere = true;
+		double x = 0, y = 0;
+		for (int k = 0; k < 3; k++) {
+			const double p = pr.o[k] + w[k] * scale - pr.ul[k];
+			x += p * pr.du[k];
+			y += p * pr.dv[k];
+		}
+		x /= pr.du2;
+		y /= pr.dv2;
+		if (!(x > -1e9 && x < 1e9 && y > -1e9 && y < 1e9))
+			everywhere = true;
+		x0 = x < x0 ? x : x0, x1 = x > x1 ? x : x1;
+		y0 = y < y0 ? y : y0, y1 = y > y1 ? y : y1;
+	}
+	if (everywhere) {
+		x0 = y0 = -1e9;
+		x1 = y1 = 1e9;
+	}
+	// widened by the margin (and by more than the rounding of these few binary64 operations)
+	x0 -= pr.margin + 1e-9 * (x0 < 0 ? -x0 : x0), x1 += pr.margin + 1e-9 * (x1 < 0 ? -x1 : x1);
+	y0 -= pr.margin + 1e-9 * (y0 < 0 ? -y0 : y0), y1 += pr.margin + 1e-9 * (y1 < 0 ? -y1 : y1);
+	// cells [i, i + 1] x [j, j + 1] of the map, whose cell (kSkyBorder, kSkyBorder) is pixel (0, 0)
+	const double lim = 1e8;
+	const long long i0 = (long long)floor(x0 < -lim ? -lim : x0) + kSkyBorder, i1 = (long long)floor(x1 > lim ? lim : x1) + kSkyBorder;
+	const long long j0 = (long long)floor(y0 < -lim ? -lim : y0) + kSkyBorder, j1 = (long long)floor(y1 > lim ? lim : y1) + kSkyBorder;
+	const int ci0 = (int)(i0 < 0 ? 0 : i0), ci1 = (int)(i1 > map_w - 1 ? map_w - 1 : i1);
+	const int cj0 = (int)(j0 < 0 ? 0 : j0), cj1 = (int)(j1 > map_h - 1 ? map_h - 1 : j1);
+	if (ci1 < ci0 || cj1 < cj0)
+		return;
+	const uint32_t ni = (uint32_t)(ci1 - ci0 + 1), nj = (uint32_t)(cj1 - cj0 + 1);
+	for (uint64_t idx = lane; idx < (uint64_t)ni * nj; idx += 64)
+		cover[(size_t)(cj0 + (int)(idx / ni)) * map_w + ci0 + (int)(idx % ni)] = 1;
+}
+
+// The pixel filter moves a sample by .5 sqrt(-2 ln u1) pixels from the pixel's
+// centre (src/main.cpp:674-683).  If every covered cell is further than that
+// from the centre, the sample's ray ends in the sky whatever its angle u2: that
+// is u1 >= exp(-2 distance^2), stored here per pixel, rounded up (rounding only
+// ever sends a sample the long way).  2 = never.  Cells beyond kSkyBorder are
+// not looked at and count as covered.
+__global__ __launch_bounds__(kBlock) void k_sky_map(const uint8_t *cover, const int width, const int height, float *sky_map)
+{
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= (uint32_t)width * (uint32_t)height)
+		return;
+	const int px = (int)(i % (uint32_t)width), py = (int)(i / (uint32_t)width), map_w = width + 2 * kSkyBorder;
+	float d2 = (kSkyBorder + .5f) * (kSkyBorder + .5f);
+	for (int dj = -kSkyBorder; dj <= kSkyBorder; dj++)
+		for (int di = -kSkyBorder; di <= kSkyBorder; di++)
+			if (cover[(size_t)(py + kSkyBorder + dj) * map_w + px + kSkyBorder + di]) {
+				const float dx = di ? (float)(di < 0 ? -di : di) - .5f : 0.f, dy = dj ? (float)(dj < 0 ? -dj : dj) - .5f : 0.f;
+				d2 = lesser(d2, dx * dx + dy * dy);
+			}
+	// __expf is good to a few ulp; the factor covers that
+	sky_map[i] = d2 > 0.f ? __expf(-2.f * d2) * (1.f + 0x1p-10f) + 0x1p-120f : 2.f;
+}
+
 // ------------------------------------------------------------------ finish
 
 // Pixel sum = block sums added in block order from zero (`resume`: from the sum
@@ -854,6 +926,17 @@ void launch_part_weights(hipStream_t s, const RenderArgs &a, uint32_t *weights, 
 void launch_advance(hipStream_t s, const RenderArgs &a, int par)
 {
 	hipLaunchKernelGGL(k_advance, dim3(blocks_for(a.n_slots)), dim3(kBlock), 0, s, a, par);
+}
+
+void launch_sky_map(hipStream_t s, const TreeRef &tree, uint32_t n_pairs, const Projection &pr, uint32_t width,
+                    uint32_t height, uint8_t *cover, float *sky_map)
+{
+	const int map_w = (int)width + 2 * kSkyBorder, map_h = (int)height + 2 * kSkyBorder;
+	(void)hipMemsetAsync(cover, 0, (size_t)map_w * map_h, s);
+	hipLaunchKernelGGL(k_cover_leaves, dim3((2 * n_pairs + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, s, tree, n_pairs,
+	                   pr, map_w, map_h, cover);
+	hipLaunchKernelGGL(k_sky_map, dim3(blocks_for((uint64_t)width * height)), dim3(kBlock), 0, s, cover, (int)width,
+	                   (int)height, sky_map);
 }
 
 void launch_intersect(hipStream_t s, const RenderArgs &a, int par, int depth, bool count)

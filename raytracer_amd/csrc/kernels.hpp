@@ -73,11 +73,10 @@ struct RenderArgs {
 	uint32_t streams_per_part;     // pixels of a part x block runs of the pass
 	uint32_t n_streams;            // in this group's list (Counters::next_item counts them out)
 	uint32_t grab_at;              // waiting lanes that make a wave draw new streams
-	// Pinhole cameras looking at a tame tree: the scene's box projects into the
-	// rectangle [box_x0, box_x1] x [box_y0, box_y1] of the image plane (pixel units,
-	// a safety margin included); box_seen = 0 when no such rectangle is known.
-	uint32_t box_seen;
-	float box_x0, box_x1, box_y0, box_y1;
+	// Pinhole cameras looking at a tame tree: per pixel, the value u1 of the pixel
+	// filter's first random number from which on a sample stays clear of every
+	// leaf's box on the image plane (see k_sky_map); null when there is no such map.
+	const float *sky_map;
 	uint32_t fast_trips;           // samples a lane may finish per pass without tracing (rays that miss the whole scene)
 	const uint32_t *part_order;    // tile * lane_blocks + part, heaviest first (see k_part_weights)
 	uint32_t spp, sps;
@@ -91,6 +90,18 @@ struct RenderArgs {
 void launch_init_slots(hipStream_t s, const RenderArgs &a, uint32_t n_slots);
 void launch_part_weights(hipStream_t s, const RenderArgs &a, uint32_t *weights, int depth);
 void launch_advance(hipStream_t s, const RenderArgs &a, int par);
+// Where a pinhole camera sees a point: on the image plane at o + (point - o) * h / ((point - o) . n),
+// pixel coordinates x = (that - ul) . du / du2, y likewise with dv.
+struct Projection {
+	double o[3], ul[3], du[3], dv[3], n[3];
+	double h, du2, dv2;
+	double margin;       // pixels by which every projected box is widened
+};
+constexpr int kSkyBorder = 3;     // cells around the frame that the cover map includes, and the search radius
+
+// cover: (width + 2 kSkyBorder) x (height + 2 kSkyBorder) bytes; sky_map: width x height floats
+void launch_sky_map(hipStream_t s, const TreeRef &tree, uint32_t n_pairs, const Projection &pr, uint32_t width,
+                    uint32_t height, uint8_t *cover, float *sky_map);
 void launch_intersect(hipStream_t s, const RenderArgs &a, int par, int depth, bool count);
 void launch_shadow(hipStream_t s, const RenderArgs &a, uint32_t bound, int depth, bool count);
 void launch_sum_blocks(hipStream_t s, const float4 *partial, const int32_t *pixels, uint32_t n_pad, uint32_t n_blocks,

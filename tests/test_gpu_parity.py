@@ -263,16 +263,25 @@ def _box_mesh(lo, hi):
     return "triangle_mesh {\n\tvertices [\n\t\t" + "\n\t\t".join(rows) + "\n\t]\n}\n"
 
 
-@pytest.mark.parametrize("camera,look_at", [("[-3 0 0.1]", "[0 0 0.1]"), ("[-2.5 1.3 0.9]", "[0 0.1 0]")])
-def test_samples_answered_from_the_pixel_filter_radius(gpu, camera, look_at):
+_SPHERES = ("sphere {\n\tcenter [0 -0.3 0.1]\n\tradius 0.45\n}\n\nsphere {\n\tcenter [0.2 0.5 -0.2]\n\tradius 0.3\n}\n\n"
+            "sphere {\n\tcenter [-0.4 0.1 0.6]\n\tradius 0.2\n}\n")
+
+
+@pytest.mark.parametrize("camera,look_at,geometry", [
+    ("[-3 0 0.1]", "[0 0 0.1]", "box"),          # seen along an axis: the outline is the projected box on all four sides
+    ("[-2.5 1.3 0.9]", "[0 0.1 0]", "box"),
+    ("[-2.2 0.4 0.3]", "[0 0 0.1]", "spheres"),
+    ("[-2.5 1.3 0.9]", "[0 1.1 0.9]", "box"),    # the mesh is cut by the edge of the frame
+])
+def test_samples_answered_on_the_image_plane(gpu, camera, look_at, geometry):
     """Camera samples whose pixel-filter radius cannot reach the projection of
-    the scene's box are given the sky without a ray.  A box-shaped mesh fills
-    its own bounding box, so its outline IS the projection's (seen along an
-    axis: all four edges), and every pixel around the outline mixes samples
-    decided either way: all must agree with the checker's full computation."""
+    any leaf's box are given the sky without a ray.  A box-shaped mesh fills
+    its own bounding box and a sphere touches all six faces of its own, so the
+    pixels around their outlines mix samples decided either way, and all must
+    agree with the checker's full computation."""
     text = ("render {\n\tcamera %s\n\tlook_at %s\n\tsamples 96\n\twidth 44\n\theight 40\n"
             "\tsky_box_color [.5 .6 1]\n}\n\nmaterial {\n\tcolor [0.8 0.3 0.2]\n\tior 1.5\n\troughness 1\n\tmetallic 0\n}\n\n"
-            % (camera, look_at)) + _box_mesh((-0.5, -0.62, -0.41), (0.5, 0.57, 0.63))
+            % (camera, look_at)) + (_box_mesh((-0.5, -0.62, -0.41), (0.5, 0.57, 0.63)) if geometry == "box" else _SPHERES)
     osc = orc.Scene.parse(text).build_bvh()
     psc = rta.Scene.parse(text).build_bvh()
     gpu.upload(psc)

@@ -215,7 +215,8 @@ typedef struct {
  * Memory: a block's sum waits (16 bytes per pixel and block) until the pixel's
  * earlier blocks are in; when all blocks together would need more than 32 GiB
  * they are rendered in passes over consecutive blocks (RTA_RENDER_SMALL_PASSES:
- * always, in the smallest passes), with the same sums.
+ * always, in the smallest passes), with the same sums.  A pinhole camera
+ * outside the scene's box adds 5 bytes per pixel (which samples need no ray).
  * accum: height*width*3 floats, per-pixel radiance SUM over samples (may be
  * NULL); bgr: height*width*3 bytes B,G,R top row first (may be NULL).  Only the
  * pixels owned by this shard are written. */

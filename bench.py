@@ -36,12 +36,16 @@ import raytracer_amd as rta  # noqa: E402
 # with the reference traversal's own visit counts per workload.
 WORKLOADS = {
     "dragon1080p": dict(scene="dragon.txt", width=1920, height=1080, spp=1024, bytes_per_ray=691.0, early_bytes=156.0,
-                        cpu_spp=256, label="scenes/dragon.txt 1920x1080 1024spp"),
+                        sps=16, cpu_spp=256, label="scenes/dragon.txt 1920x1080 1024spp"),
     "cornell1080p": dict(scene="cornell_box.txt", width=1920, height=1080, spp=256, bytes_per_ray=764.0, early_bytes=104.0,
-                         cpu_spp=64, label="scenes/cornell_box.txt 1920x1080 256spp"),
+                         sps=16, cpu_spp=64, label="scenes/cornell_box.txt 1920x1080 256spp"),
     "dragon4k": dict(scene="dragon.txt", width=3840, height=2160, spp=4096, bytes_per_ray=691.0, early_bytes=156.0,
-                     cpu_spp=64, label="scenes/dragon.txt 3840x2160 4096spp"),
+                     sps=32, cpu_spp=64, label="scenes/dragon.txt 3840x2160 4096spp"),
 }
+# sps: samples per random stream.  A stream's samples are a sequential chain (one wavefront step per
+# path segment), so shorter streams mean more chains in flight and a shorter end of the render, at
+# 16 bytes of block sum per stream: 1080p x 1024 spp runs at 12.3 / 12.3 / 11.5 / 10.2 Grays/s with
+# 8 / 16 / 32 / 64 samples per stream; the 4K frame has streams enough either way (13.4 / 13.7).
 # early_bytes: what the reference traversal moves for a closest-hit query that the GPU path answers
 # without a traversal (a camera ray that misses every leaf's box): 40 B ray and hit + 64 B per node
 # visit.  One visit on cornell (its root has two leaves); 1.8 on average on dragon = the reference's
@@ -92,7 +96,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="dragon1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel per GPU")
-    ap.add_argument("--samples-per-stream", type=int, default=32)
+    ap.add_argument("--samples-per-stream", type=int, default=0, help="0: the workload's own (16 or 32)")
     ap.add_argument("--slots", type=int, default=0)
     ap.add_argument("--run-blocks", type=int, default=0)
     ap.add_argument("--streams", type=int, default=0)
@@ -117,6 +121,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     w = dict(WORKLOADS[args.workload])
+    args.samples_per_stream = args.samples_per_stream or w["sps"]
     spp_per_gpu = args.spp or w["spp"]
     spp = spp_per_gpu * world              # weak scaling: per-GPU samples fixed
     width, height = w["width"], w["height"]

@@ -49,6 +49,8 @@ namespace {
 constexpr uint32_t kWaiting = 0xfffffffdu;     // through with its blocks; waits for the wave's next tile
 constexpr uint32_t kRetired = 0xfffffffeu;     // no work left for this wave
 constexpr uint32_t kEnded = 0xffffffffu;       // path finished, its occlusion query pending; retired by the next pass
+// k_sky_map values up to this say that no sample of the pixel can reach a leaf's box (u1 >= 2^-24 > this)
+constexpr float kNoSampleReaches = 0x1p-25f;
 // kinds of closest-hit rays, queued apart; kOddRays are the (rare) rays whose
 // box tests need the division-based form (see ray_is_tame), of either origin
 constexpr int kCameraRays = 0, kBounceRays = 1, kOddRays = 2;
@@ -347,6 +349,7 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 	bool need_ray = false, have_ray = false, in_registers = false, meta_changed = false;
 	uint32_t answered_here = 0;
 	uint32_t sky_pixel = 0xffffffffu, sky_pu = 0, sky_pv = 0;     // the pixel sky_u1 belongs to
+	uint32_t repeat = 1;          // samples that the finished sample stands for
 	float sky_u1 = 2.f;
 	for (uint32_t trip = 0;; trip++) {
 		if (ended) {
@@ -356,10 +359,13 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 				A = a.acc[slot];
 				in_registers = true;
 			}
-			uint32_t done = __float_as_uint(A.w) + 1;
-			A.x += color.x;
-			A.y += color.y;
-			A.z += color.z;
+			uint32_t done = __float_as_uint(A.w) + repeat;
+			for (uint32_t r = 0; r < repeat; r++) {      // (1, or the rest of a block of sky samples)
+				A.x += color.x;
+				A.y += color.y;
+				A.z += color.z;
+			}
+			repeat = 1;
 			const uint32_t first = M.y * a.sps;
 			const uint32_t len = a.spp - first < a.sps ? a.spp - first : a.sps;
 			need_ray = true;
@@ -439,9 +445,16 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 				sky_pv = M.x / a.width;
 				sky_u1 = a.sky_map ? a.sky_map[M.x] : 2.f;
 			}
-			const CameraDraws draws = camera_draws(a, rng);
-			if (trip < a.fast_trips && draws.u1 >= sky_u1) {
-				answered = true;      // too close to the pixel's centre to reach the scene's box
+			if (trip < a.fast_trips && sky_u1 <= kNoSampleReaches) {
+				// Every sample of this pixel ends in the sky (u1 is a positive multiple of
+				// 2^-24): the rest of the block is the sky's colour added once per sample,
+				// and its random numbers are never looked at (the next block has its own seed).
+				const uint32_t first = M.y * a.sps;
+				const uint32_t len = a.spp - first < a.sps ? a.spp - first : a.sps;
+				repeat = len - __float_as_uint(A.w);
+				answered = true;
+			} else if (const CameraDraws draws = camera_draws(a, rng); trip < a.fast_trips && draws.u1 >= sky_u1) {
+				answered = true;      // too close to the pixel's centre to reach any leaf's box
 			} else {
 				next_ray = camera_ray(a, sky_pu, sky_pv, draws);
 				have_ray = true;
@@ -455,7 +468,7 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 			ended = true;
 			need_ray = false;
 			have_ray = false;
-			answered_here++;
+			answered_here += repeat;
 		}
 	}
 

@@ -805,7 +805,11 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	base.run_blocks = run_blocks;
 	base.lane_blocks = lane_blocks;
 	base.part_order = ctx->part_order.as<const uint32_t>();
-	base.fast_trips = 64;         // measured on dragon.txt: 4 loses 4 %, 32 and 128 are within 1 %
+	// per pass of k_advance a lane may finish so many sample blocks of pixels that only see the sky,
+	// and so many single samples that need no ray (measured on dragon.txt: 2-4 best, 64 loses 2 %:
+	// the wave's other lanes wait with their rays meanwhile)
+	base.bulk_trips = 64;
+	base.fast_trips = 4;
 	base.spp = spp;
 	base.sps = sps;
 	base.width = (uint32_t)p->width;
@@ -880,20 +884,37 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	// Heaviest parts of the image first: one ray per pixel tells which parts see
 	// geometry, a counting sort (stable, so equal parts keep their order) makes the
 	// list the waves draw their items from.
+	uint32_t n_listed = 0, n_far = 0;
+	uint64_t far_pixels = 0;
 	if (n_parts) {
 		std::vector<uint32_t> weight(n_parts), order(n_parts);
 		launch_part_weights(s, ga[0], ctx->part_weights.as<uint32_t>(), ctx->stack_depth);
 		HIP_TRY_R(hipMemcpyAsync(weight.data(), ctx->part_weights.ptr, (size_t)n_parts * 4, hipMemcpyDeviceToHost, s));
 		HIP_TRY_R(hipStreamSynchronize(s));
+		// parts that only see the sky come off the list: their block sums are written
+		// by k_fill_far, pass by pass
+		std::vector<uint32_t> far;
 		uint32_t start[66] = {0};
 		for (uint32_t w : weight)
-			start[64 - std::min(w, 64u) + 1]++;
+			if (w != kNothingToTrace)
+				start[64 - std::min(w, 64u) + 1]++;
 		for (int k = 1; k < 66; k++)
 			start[k] += start[k - 1];
 		for (uint32_t k = 0; k < n_parts; k++)
-			order[start[64 - std::min(weight[k], 64u)]++] = k;
-		HIP_TRY_R(hipMemcpyAsync(ctx->part_order.ptr, order.data(), (size_t)n_parts * 4, hipMemcpyHostToDevice, s));
-		HIP_TRY_R(hipStreamSynchronize(s));       // `order` dies here
+			if (weight[k] != kNothingToTrace)
+				order[start[64 - std::min(weight[k], 64u)]++] = k;
+			else
+				far.push_back(k);
+		n_far = (uint32_t)far.size();
+		n_listed = n_parts - n_far;
+		const uint32_t part_pixels = 64 / lane_blocks;
+		for (uint32_t which : far)
+			for (uint32_t k = 0; k < part_pixels; k++)
+				far_pixels += px[(size_t)(which / lane_blocks) * 64 + (which % lane_blocks) * part_pixels + k] >= 0;
+		HIP_TRY_R(hipMemcpyAsync(ctx->part_order.ptr, order.data(), (size_t)n_listed * 4, hipMemcpyHostToDevice, s));
+		// (the weights are through; their buffer takes the other list)
+		HIP_TRY_R(hipMemcpyAsync(ctx->part_weights.ptr, far.data(), (size_t)n_far * 4, hipMemcpyHostToDevice, s));
+		HIP_TRY_R(hipStreamSynchronize(s));       // `order` and `far` die here
 	}
 	HIP_TRY_R(hipEventRecord(ev_mid, s));
 	for (int g = 1; g < groups; g++)
@@ -933,10 +954,20 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		}
 		HIP_TRY_R(hipMemcpyAsync(ctx->counters.ptr, ctx->host_counters, sizeof(Counters) * kMaxGroups, hipMemcpyHostToDevice, s));
 		HIP_TRY_R(hipStreamSynchronize(s));       // host_counters is reused for read-back below; the groups are idle
+		if (n_far) {
+			RenderArgs fill = base;
+			fill.first_block = first_block;
+			launch_fill_far(s, fill, ctx->part_weights.as<const uint32_t>(), n_far, first_block, end_block);
+			// each of these samples stands for one NearestHit call of the reference, like
+			// the ones k_advance answers
+			const uint64_t pass_samples = std::min<uint64_t>(spp, (uint64_t)end_block * sps) - (uint64_t)first_block * sps;
+			st.rays += far_pixels * pass_samples;
+			st.early_rays += far_pixels * pass_samples;
+		}
 		for (int g = 0; g < groups; g++) {
 			// the sorted parts are dealt round-robin to the slot groups; a part's
 			// streams are its pixels x the block runs of the pass
-			const uint32_t parts_here = (n_parts + (uint32_t)groups - 1 - (uint32_t)g) / (uint32_t)groups;
+			const uint32_t parts_here = (n_listed + (uint32_t)groups - 1 - (uint32_t)g) / (uint32_t)groups;
 			ga[g].first_block = first_block;
 			ga[g].end_block = end_block;
 			ga[g].group = (uint32_t)g;

@@ -445,7 +445,7 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 				sky_pv = M.x / a.width;
 				sky_u1 = a.sky_map ? a.sky_map[M.x] : 2.f;
 			}
-			if (trip < a.fast_trips && sky_u1 <= kNoSampleReaches) {
+			if (trip < a.bulk_trips && sky_u1 <= kNoSampleReaches) {
 				// Every sample of this pixel ends in the sky (u1 is a positive multiple of
 				// 2^-24): the rest of the block is the sky's colour added once per sample,
 				// and its random numbers are never looked at (the next block has its own seed).
@@ -650,7 +650,9 @@ __global__ __launch_bounds__(kBlock) void k_part_weights(const RenderArgs a, uin
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;      // index in the padded pixel list
 	const int32_t pixel = i < a.n_pad ? a.pixels[i] : -1;
 	bool seen = false;
-	if (pixel >= 0) {
+	// pixels none of whose samples can reach a leaf's box need no slot at all (k_fill_far)
+	const bool near = pixel >= 0 && !(a.sky_map && a.sky_map[pixel] <= kNoSampleReaches);
+	if (near) {
 		const uint32_t pu = (uint32_t)pixel % a.width, pv = (uint32_t)pixel / a.width;
 		const V3 o = mk(a.cam.origin[0], a.cam.origin[1], a.cam.origin[2]);
 		const V3 ul = mk(a.cam.upper_left[0], a.cam.upper_left[1], a.cam.upper_left[2]);
@@ -664,11 +666,43 @@ __global__ __launch_bounds__(kBlock) void k_part_weights(const RenderArgs a, uin
 	}
 	// a wave covers one tile; its lanes split into lane_blocks parts of 64 / lane_blocks pixels
 	const uint32_t part_pixels = 64 / a.lane_blocks, lane = threadIdx.x & 63;
-	const unsigned long long votes = __ballot(seen);
+	const unsigned long long votes = __ballot(seen), any_near = __ballot(near);
 	if (i < a.n_pad && lane % part_pixels == 0) {
 		const unsigned long long mask = part_pixels == 64 ? ~0ull : ((1ull << part_pixels) - 1) << lane;
-		weights[(i / 64) * a.lane_blocks + lane / part_pixels] = (uint32_t)__popcll(votes & mask);
+		weights[(i / 64) * a.lane_blocks + lane / part_pixels] =
+		    (any_near & mask) ? (uint32_t)__popcll(votes & mask) : kNothingToTrace;
 	}
+}
+
+// The block sums of pixels that only see the sky: the sky's colour (src/main.cpp:
+// 511-514 with throughput 1 and radiance 0) added once per sample of the block,
+// in the order and precision of the per-sample path.  One thread per (block,
+// listed part, pixel of the part).
+__global__ __launch_bounds__(kBlock) void k_fill_far(const RenderArgs a, const uint32_t *far_parts, const uint32_t n_far,
+                                                    const uint32_t first_block, const uint32_t end_block)
+{
+	const uint32_t part_pixels = 64 / a.lane_blocks;
+	const uint64_t per_block = (uint64_t)n_far * part_pixels;
+	const uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+	if (gid >= per_block * (end_block - first_block))
+		return;
+	const uint32_t block = first_block + (uint32_t)(gid / per_block);
+	const uint32_t r = (uint32_t)(gid % per_block);
+	const uint32_t which = far_parts[r / part_pixels];
+	const uint32_t tile = which / a.lane_blocks, part = which - tile * a.lane_blocks;
+	const uint32_t padded = tile * 64 + part * part_pixels + r % part_pixels;
+	if (a.pixels[padded] < 0)
+		return;
+	const uint32_t first = block * a.sps;
+	const uint32_t len = a.spp - first < a.sps ? a.spp - first : a.sps;
+	const V3 color = mk(0, 0, 0) + mk(1, 1, 1) * mk(a.sky[0], a.sky[1], a.sky[2]);
+	float4 A = make_float4(0.f, 0.f, 0.f, 0.f);
+	for (uint32_t k = 0; k < len; k++) {
+		A.x += color.x;
+		A.y += color.y;
+		A.z += color.z;
+	}
+	a.partial[(size_t)(block - a.first_block) * a.n_pad + padded] = A;
 }
 
 // ------------------------------------------------------------------ sky map
@@ -929,6 +963,14 @@ static inline size_t stack_bytes(int depth) { return (size_t)depth * kBlock * si
 void launch_init_slots(hipStream_t s, const RenderArgs &a, uint32_t n_slots)
 {
 	hipLaunchKernelGGL(k_init_slots, dim3(blocks_for(n_slots)), dim3(kBlock), 0, s, a, n_slots);
+}
+
+void launch_fill_far(hipStream_t s, const RenderArgs &a, const uint32_t *far_parts, uint32_t n_far, uint32_t first_block,
+                     uint32_t end_block)
+{
+	const uint64_t n = (uint64_t)n_far * (64 / a.lane_blocks) * (end_block - first_block);
+	if (n)
+		hipLaunchKernelGGL(k_fill_far, dim3(blocks_for(n)), dim3(kBlock), 0, s, a, far_parts, n_far, first_block, end_block);
 }
 
 void launch_part_weights(hipStream_t s, const RenderArgs &a, uint32_t *weights, int depth)

@@ -77,7 +77,8 @@ struct RenderArgs {
 	// filter's first random number from which on a sample stays clear of every
 	// leaf's box on the image plane (see k_sky_map); null when there is no such map.
 	const float *sky_map;
-	uint32_t fast_trips;           // samples a lane may finish per pass without tracing (rays that miss the whole scene)
+	uint32_t bulk_trips;           // whole sample blocks a lane may finish per pass (pixels that only see the sky)
+	uint32_t fast_trips;           // single samples a lane may finish per pass without tracing
 	const uint32_t *part_order;    // tile * lane_blocks + part, heaviest first (see k_part_weights)
 	uint32_t spp, sps;
 	uint32_t width;
@@ -89,6 +90,11 @@ struct RenderArgs {
 
 void launch_init_slots(hipStream_t s, const RenderArgs &a, uint32_t n_slots);
 void launch_part_weights(hipStream_t s, const RenderArgs &a, uint32_t *weights, int depth);
+// weight of a part none of whose pixels can send a sample to a leaf's box (see k_sky_map)
+constexpr uint32_t kNothingToTrace = 0xffffffffu;
+// block sums of the blocks first_block..end_block-1 for the pixels of the `n_far` parts listed in far_parts
+void launch_fill_far(hipStream_t s, const RenderArgs &a, const uint32_t *far_parts, uint32_t n_far, uint32_t first_block,
+                     uint32_t end_block);
 void launch_advance(hipStream_t s, const RenderArgs &a, int par);
 // Where a pinhole camera sees a point: on the image plane at o + (point - o) * h / ((point - o) . n),
 // pixel coordinates x = (that - ul) . du / du2, y likewise with dv.

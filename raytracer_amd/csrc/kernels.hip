@@ -676,33 +676,37 @@ __global__ __launch_bounds__(kBlock) void k_part_weights(const RenderArgs a, uin
 
 // The block sums of pixels that only see the sky: the sky's colour (src/main.cpp:
 // 511-514 with throughput 1 and radiance 0) added once per sample of the block,
-// in the order and precision of the per-sample path.  One thread per (block,
-// listed part, pixel of the part).
+// in the order and precision of the per-sample path.  One thread per (listed
+// part, pixel of the part) writes all blocks of the pass.
 __global__ __launch_bounds__(kBlock) void k_fill_far(const RenderArgs a, const uint32_t *far_parts, const uint32_t n_far,
                                                     const uint32_t first_block, const uint32_t end_block)
 {
 	const uint32_t part_pixels = 64 / a.lane_blocks;
-	const uint64_t per_block = (uint64_t)n_far * part_pixels;
 	const uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-	if (gid >= per_block * (end_block - first_block))
+	if (gid >= (uint64_t)n_far * part_pixels)
 		return;
-	const uint32_t block = first_block + (uint32_t)(gid / per_block);
-	const uint32_t r = (uint32_t)(gid % per_block);
-	const uint32_t which = far_parts[r / part_pixels];
+	const uint32_t which = far_parts[gid / part_pixels];
 	const uint32_t tile = which / a.lane_blocks, part = which - tile * a.lane_blocks;
-	const uint32_t padded = tile * 64 + part * part_pixels + r % part_pixels;
+	const uint32_t padded = tile * 64 + part * part_pixels + (uint32_t)(gid % part_pixels);
 	if (a.pixels[padded] < 0)
 		return;
-	const uint32_t first = block * a.sps;
-	const uint32_t len = a.spp - first < a.sps ? a.spp - first : a.sps;
 	const V3 color = mk(0, 0, 0) + mk(1, 1, 1) * mk(a.sky[0], a.sky[1], a.sky[2]);
 	float4 A = make_float4(0.f, 0.f, 0.f, 0.f);
-	for (uint32_t k = 0; k < len; k++) {
-		A.x += color.x;
-		A.y += color.y;
-		A.z += color.z;
+	uint32_t summed = 0;
+	for (uint32_t block = first_block; block < end_block; block++) {
+		const uint32_t first = block * a.sps;
+		const uint32_t len = a.spp - first < a.sps ? a.spp - first : a.sps;
+		if (len != summed) {      // (all blocks but the image's last have sps samples)
+			A = make_float4(0.f, 0.f, 0.f, 0.f);
+			for (uint32_t k = 0; k < len; k++) {
+				A.x += color.x;
+				A.y += color.y;
+				A.z += color.z;
+			}
+			summed = len;
+		}
+		a.partial[(size_t)(block - first_block) * a.n_pad + padded] = A;
 	}
-	a.partial[(size_t)(block - a.first_block) * a.n_pad + padded] = A;
 }
 
 // ------------------------------------------------------------------ sky map
@@ -968,7 +972,7 @@ void launch_init_slots(hipStream_t s, const RenderArgs &a, uint32_t n_slots)
 void launch_fill_far(hipStream_t s, const RenderArgs &a, const uint32_t *far_parts, uint32_t n_far, uint32_t first_block,
                      uint32_t end_block)
 {
-	const uint64_t n = (uint64_t)n_far * (64 / a.lane_blocks) * (end_block - first_block);
+	const uint64_t n = (uint64_t)n_far * (64 / a.lane_blocks);
 	if (n)
 		hipLaunchKernelGGL(k_fill_far, dim3(blocks_for(n)), dim3(kBlock), 0, s, a, far_parts, n_far, first_block, end_block);
 }

@@ -549,7 +549,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 		const uint32_t shard = blockIdx.x % kShards, part = blockIdx.x / kShards;
 		const uint32_t q = ray_queue_index(par, kBounceRays, shard);
 		const uint32_t total = a.cnt->n_ray[q];
-		if (part < pulling_blocks(total, a.rays_per_lane)) {
+		// a short list is spread over up to 8 workgroups rather than worked through by
+		// one: towards the end of a render the steps are as long as their longest wave
+		const uint32_t spread = (total + 8 * kBlock - 1) / (8 * kBlock);
+		const uint32_t rays_per_lane = spread < a.rays_per_lane ? (spread ? spread : 1u) : a.rays_per_lane;
+		if (part < pulling_blocks(total, rays_per_lane)) {
 			const uint32_t *queue = a.q_ray + (size_t)q * a.shard_cap;
 			traverse_pulling<false, COUNT, true>(
 			    a.tree, a.refill_at, lds_stack + threadIdx.x, depth, wc,

@@ -236,6 +236,8 @@ def main():
                     # (profiled wave instructions per ray x 4 cycles, 1024 SIMDs at 2.4 GHz)
                     line["roofline"]["valu_busy_frac"] = (tj["valu_wave_instructions_per_ray"] * 4.0 * rays_all /
                                                           elapsed / world / (1024 * 2.4e9))
+                    line["roofline"]["valu_busy_note"] = ("profiled wave instructions x 4 cycles / SIMD cycles; above 1 "
+                                                          "when sparsely populated instructions issue in fewer cycles")
         if args.count_work and tot["rays"]:
             line["roofline"]["measured_bytes_per_ray"] = (64.0 * tot["inner_visits"] + 36.0 * tot["tri_tests"] +
                                                           16.0 * tot["sph_tests"]) / (tot["rays"] +

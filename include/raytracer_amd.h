@@ -158,7 +158,10 @@ typedef struct {
 
 /* Closest hit of n rays (6 floats each: origin xyz, direction xyz).  Replaces
  * NearestHit (src/main.cpp:332-422) with the same tree, visit order, tie rule
- * and arithmetic, so prim/t/u/v equal the reference's bit for bit. */
+ * and arithmetic, so prim/t/u/v equal the reference's bit for bit.  Batches of
+ * 65536 rays and more over a tree of more than 8 MiB are traced in the order
+ * of their origins (16 bytes of workspace per ray) unless they come in that
+ * order; hits[i] always belongs to ray i. */
 int rta_trace_closest(rta_context *ctx, const float *rays, int64_t n, rta_hit *hits, int mem);
 
 /* Any hit closer than tmax[i].  Replaces Occluded (src/main.cpp:424-478). */

@@ -85,6 +85,7 @@ struct rta_context {
 	DeviceBuffer ray0, ray1, hit, thr, col, rng, acc, meta, q_ray, shadow, partial, pixels, frame, bgr, counters;
 	DeviceBuffer part_weights, part_order;
 	DeviceBuffer cover, sky_map;         // see k_sky_map
+	DeviceBuffer ray_order;              // see tracing_order
 	DeviceBuffer io_a, io_b, io_c;       // staging for host-pointer calls
 	Counters *host_counters = nullptr;    // pinned, kMaxGroups entries
 
@@ -500,6 +501,35 @@ int64_t rta_shard_pixels(int32_t width, int32_t height, int32_t shard_index, int
 
 // ------------------------------------------------------------------ ray batches
 
+// Big batches over a tree that does not fit the caches are traced in the order
+// of sort_rays.hip (same results, each ray is traced on its own).  Sets `order`
+// to the device array of ray numbers, or to null when the batch is traced as it
+// comes: small batches, small trees (the order costs more than it saves) and
+// trees without a known box.
+static int tracing_order(rta_context *ctx, const float *d_rays, int64_t n, const uint32_t *&order)
+{
+	order = nullptr;
+	const size_t tree_bytes = (size_t)ctx->n_pairs * 64 + (size_t)ctx->n_prims * 48;
+	if (!ctx->box_known || n < (1 << 16) || n >= ((int64_t)1 << 32) || tree_bytes < ((size_t)8 << 20))
+		return RTA_OK;
+	const uint32_t count = (uint32_t)n;
+	const size_t temp = (ray_order_temp_bytes(count) + 255) & ~(size_t)255, each = ((size_t)count * 4 + 255) & ~(size_t)255;
+	HIP_TRY(ctx, ctx->ray_order.reserve(4 * each + temp + 256));
+	char *base = ctx->ray_order.as<char>();
+	uint32_t *keys = (uint32_t *)base, *keys_sorted = (uint32_t *)(base + each), *index = (uint32_t *)(base + 2 * each),
+	         *sorted = (uint32_t *)(base + 3 * each), *descents = (uint32_t *)(base + 4 * each + temp);
+	launch_ray_keys(ctx->stream, d_rays, count, ctx->box, ctx->box + 3, keys, index, descents);
+	// a batch that comes in order (a camera's rays, say) is not sorted again
+	uint32_t out_of_order = 0;
+	HIP_TRY(ctx, hipMemcpyAsync(&out_of_order, descents, sizeof out_of_order, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	if ((uint64_t)out_of_order * 16 < count)
+		return RTA_OK;
+	HIP_TRY(ctx, launch_ray_sort(ctx->stream, count, keys, keys_sorted, index, sorted, base + 4 * each, temp));
+	order = sorted;
+	return RTA_OK;
+}
+
 int rta_trace_closest(rta_context *ctx, const float *rays, int64_t n, rta_hit *hits, int mem)
 {
 	if (!ctx)
@@ -522,7 +552,10 @@ int rta_trace_closest(rta_context *ctx, const float *rays, int64_t n, rta_hit *h
 		d_rays = ctx->io_a.as<const float>();
 		d_hits = ctx->io_b.as<rta_hit>();
 	}
-	launch_batch_closest(ctx->stream, tree_of(ctx), d_rays, (uint64_t)n, d_hits, ctx->stack_depth, nullptr);
+	const uint32_t *order = nullptr;
+	if (int rc = tracing_order(ctx, d_rays, n, order))
+		return rc;
+	launch_batch_closest(ctx->stream, tree_of(ctx), d_rays, (uint64_t)n, d_hits, ctx->stack_depth, nullptr, order);
 	HIP_TRY(ctx, hipGetLastError());
 	if (mem == RTA_MEM_HOST)
 		HIP_TRY(ctx, hipMemcpyAsync(hits, d_hits, (size_t)n * sizeof(rta_hit), hipMemcpyDeviceToHost, ctx->stream));
@@ -578,7 +611,10 @@ int rta_trace_occluded(rta_context *ctx, const float *rays, const float *tmax, i
 		d_tmax = ctx->io_b.as<const float>();
 		d_out = ctx->io_c.as<uint8_t>();
 	}
-	launch_batch_occluded(ctx->stream, tree_of(ctx), d_rays, d_tmax, (uint64_t)n, d_out, ctx->stack_depth);
+	const uint32_t *order = nullptr;
+	if (int rc = tracing_order(ctx, d_rays, n, order))
+		return rc;
+	launch_batch_occluded(ctx->stream, tree_of(ctx), d_rays, d_tmax, (uint64_t)n, d_out, ctx->stack_depth, order);
 	HIP_TRY(ctx, hipGetLastError());
 	if (mem == RTA_MEM_HOST)
 		HIP_TRY(ctx, hipMemcpyAsync(out, d_out, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));

@@ -889,7 +889,7 @@ constexpr uint32_t kBatchRefillAt = 16;
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_batch_closest(const DeviceTree tree, const float *rays, uint64_t n,
                                                           rta_hit *hits, const int depth, Counters *cnt,
-                                                          const uint32_t rays_per_lane)
+                                                          const uint32_t rays_per_lane, const uint32_t *order)
 {
 	extern __shared__ uint32_t lds_stack[];
 	// wave w of the grid owns rays [w 64 kBatchRaysPerLane, (w + 1) 64 kBatchRaysPerLane)
@@ -897,12 +897,16 @@ __global__ __launch_bounds__(kBlock) void k_batch_closest(const DeviceTree tree,
 	const uint64_t begin = ((uint64_t)blockIdx.x * (kBlock / 64) + threadIdx.x / 64) * per_wave;
 	WorkCount wc = {0, 0, 0};
 	if (begin < n) {
-		const float *mine = rays + begin * 6;
-		rta_hit *out = hits + begin;
+		// the wave's rays: numbers begin.. of the batch, or of the tracing order
+		const float *mine = order ? rays : rays + begin * 6;
+		rta_hit *out = order ? hits : hits + begin;
+		const uint32_t *which = order ? order + begin : nullptr;
 		traverse_pulling<false, COUNT, false>(
 		    tree, kBatchRefillAt, lds_stack + threadIdx.x, depth, wc,
 		    OwnChunk{(uint32_t)(n - begin < per_wave ? n - begin : per_wave), 0u},
 		    [&](uint32_t i, Ray &ray, float &limit) {
+			    if (which)
+				    i = which[i];
 			    const float *r = mine + (size_t)i * 6;
 			    ray = Ray{mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5])};
 			    limit = FLT_MAX;
@@ -916,20 +920,23 @@ __global__ __launch_bounds__(kBlock) void k_batch_closest(const DeviceTree tree,
 
 __global__ __launch_bounds__(kBlock) void k_batch_occluded(const DeviceTree tree, const float *rays, const float *tmax,
                                                            uint64_t n, uint8_t *out, const int depth,
-                                                           const uint32_t rays_per_lane)
+                                                           const uint32_t rays_per_lane, const uint32_t *order)
 {
 	extern __shared__ uint32_t lds_stack[];
 	const uint64_t per_wave = 64 * (uint64_t)rays_per_lane;
 	const uint64_t begin = ((uint64_t)blockIdx.x * (kBlock / 64) + threadIdx.x / 64) * per_wave;
 	if (begin >= n)
 		return;
-	const float *mine = rays + begin * 6, *limits = tmax + begin;
-	uint8_t *flags = out + begin;
+	const float *mine = order ? rays : rays + begin * 6, *limits = order ? tmax : tmax + begin;
+	uint8_t *flags = order ? out : out + begin;
+	const uint32_t *which = order ? order + begin : nullptr;
 	WorkCount wc = {0, 0, 0};
 	traverse_pulling<true, false, false>(
 	    tree, kBatchRefillAt, lds_stack + threadIdx.x, depth, wc,
 	    OwnChunk{(uint32_t)(n - begin < per_wave ? n - begin : per_wave), 0u},
 	    [&](uint32_t i, Ray &ray, float &limit) {
+		    if (which)
+			    i = which[i];
 		    const float *r = mine + (size_t)i * 6;
 		    ray = Ray{mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5])};
 		    limit = limits[i];
@@ -1040,21 +1047,21 @@ void launch_resolve(hipStream_t s, const float *frame, const int32_t *pixels, ui
 }
 
 void launch_batch_closest(hipStream_t s, const TreeRef &tree, const float *rays, uint64_t n, rta_hit *hits, int depth,
-                          Counters *cnt)
+                          Counters *cnt, const uint32_t *order)
 {
 	if (cnt)
 		hipLaunchKernelGGL(k_batch_closest<true>, dim3(batch_blocks(n)), dim3(kBlock), stack_bytes(depth), s, tree, rays,
-		                   n, hits, depth, cnt, batch_rays_per_lane(n));
+		                   n, hits, depth, cnt, batch_rays_per_lane(n), order);
 	else
 		hipLaunchKernelGGL(k_batch_closest<false>, dim3(batch_blocks(n)), dim3(kBlock), stack_bytes(depth), s, tree,
-		                   rays, n, hits, depth, cnt, batch_rays_per_lane(n));
+		                   rays, n, hits, depth, cnt, batch_rays_per_lane(n), order);
 }
 
 void launch_batch_occluded(hipStream_t s, const TreeRef &tree, const float *rays, const float *tmax, uint64_t n,
-                           uint8_t *out, int depth)
+                           uint8_t *out, int depth, const uint32_t *order)
 {
 	hipLaunchKernelGGL(k_batch_occluded, dim3(batch_blocks(n)), dim3(kBlock), stack_bytes(depth), s, tree, rays, tmax, n,
-	                   out, depth, batch_rays_per_lane(n));
+	                   out, depth, batch_rays_per_lane(n), order);
 }
 
 void launch_arith(hipStream_t s, int op, const float *x, const float *y, float *out, uint64_t n)

@@ -114,10 +114,17 @@ void launch_sum_blocks(hipStream_t s, const float4 *partial, const int32_t *pixe
                        float *frame, bool resume);
 void launch_resolve(hipStream_t s, const float *frame, const int32_t *pixels, uint32_t n, float samples, float exposure,
                     uint8_t *bgr);
+// `order`: null, or the n ray numbers in the order in which they are to be traced (n < 2^32)
 void launch_batch_closest(hipStream_t s, const TreeRef &tree, const float *rays, uint64_t n, rta_hit *hits, int depth,
-                          Counters *cnt);
+                          Counters *cnt, const uint32_t *order = nullptr);
 void launch_batch_occluded(hipStream_t s, const TreeRef &tree, const float *rays, const float *tmax, uint64_t n,
-                           uint8_t *out, int depth);
+                           uint8_t *out, int depth, const uint32_t *order = nullptr);
+// sort_rays.hip: the tracing order of a big batch (by origin cell and direction octant)
+size_t ray_order_temp_bytes(uint32_t n);
+void launch_ray_keys(hipStream_t s, const float *rays, uint32_t n, const float box_lo[3], const float box_hi[3], uint32_t *keys,
+                     uint32_t *index, uint32_t *descents);
+hipError_t launch_ray_sort(hipStream_t s, uint32_t n, uint32_t *keys, uint32_t *keys_sorted, uint32_t *index, uint32_t *order,
+                           void *temp, size_t temp_bytes);
 void launch_arith(hipStream_t s, int op, const float *x, const float *y, float *out, uint64_t n);
 // variants.hip: closest hit with one design decision changed (1 private stack,
 // 2 division-based box test, 3 reference node layout); measurement only

@@ -314,6 +314,10 @@ def test_triangle_soup_indices_bit_exact(gpu):
         assert np.array_equal(bits(hits["t"]), bits(t)), label
         assert np.array_equal(bits(hits["u"]), bits(u)) and np.array_equal(bits(hits["v"]), bits(v)), label
         assert 0.05 < (idx >= 0).mean() < 0.999, label
+        # occlusion queries over the same rays, cut off at and shortly before the hits found above (the
+        # incoherent batch is big enough to be traced in the order of its origins, the grid comes in order)
+        tmax = np.where(idx >= 0, t * np.float32(1.0 if label == "coherent" else 0.999), np.float32(2.5)).astype(np.float32)
+        assert np.array_equal(gpu.trace_occluded(rr, tmax), osc.trace_occluded(rr, tmax)), label
 
 
 @pytest.mark.parametrize("name,spp", [("dragon.txt", 8), ("cornell_box.txt", 2)])

@@ -339,11 +339,11 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 	}
 
 	// Retire, draw new streams, generate - and again, for as long as some lane's
-	// new camera ray provably misses the whole scene: such a sample is over at
-	// once (src/main.cpp:511-514 with throughput 1 and radiance 0), so streams over
-	// empty sky run through many samples per pass without a queue entry, a
-	// traversal or a word of slot state moved.  Lanes whose ray must be traced keep
-	// it and wait for the loop to end.
+	// new camera sample provably ends in the sky (it cannot reach a leaf's box by
+	// sky_map, or its ray misses the box around the whole scene): such a sample is
+	// over at once (src/main.cpp:511-514 with throughput 1 and radiance 0), without
+	// a queue entry, a traversal or a word of slot state moved.  Lanes whose ray must
+	// be traced keep it and wait for the loop to end, hence the small fast_trips.
 	uint4 M = make_uint4(0u, 0u, 0u, 0u);     // pixel, current block, end of the block run, index in the padded pixel list
 	float4 A = make_float4(0.f, 0.f, 0.f, 0.f);     // block sum, samples finished in the block
 	bool need_ray = false, have_ray = false, in_registers = false, meta_changed = false;

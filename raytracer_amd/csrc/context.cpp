@@ -860,6 +860,8 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		HIP_TRY(ctx, ctx->sky_map.reserve(frame_px * 4));
 		base.sky_map = ctx->sky_map.as<const float>();
 	}
+	// long leaves (4 primitives and more on average): see traverse_leafwise
+	base.leafwise = (uint64_t)ctx->n_prims >= 4 * ((uint64_t)ctx->n_pairs + 1) ? 1u : 0u;
 	base.rays_per_lane = 8;       // measured on dragon.txt: 4 and 12 lose 1-2 %
 	base.refill_at = 24;          // likewise 16 (8 loses 3 %)
 

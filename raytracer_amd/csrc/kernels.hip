@@ -588,6 +588,36 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 		count_flush(a.cnt, wc);
 }
 
+// k_intersect for trees with long leaves (RenderArgs::leafwise): bounce and
+// camera rays alike take one lane each through traverse_leafwise.  Grid: one
+// workgroup per kBlock entries of the bounce sub-queues, then of the camera
+// sub-queues, shards innermost.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_intersect_leafwise(const RenderArgs a, const int par, const int depth)
+{
+	extern __shared__ uint32_t lds_stack[];
+	if (blockIdx.x == 0)
+		step_housekeeping(a, par);
+	const uint32_t per_kind = kShards * (a.shard_cap / kBlock);
+	const int kind = blockIdx.x < per_kind ? kBounceRays : kCameraRays;
+	const uint32_t rem = blockIdx.x < per_kind ? blockIdx.x : blockIdx.x - per_kind;
+	const uint32_t shard = rem % kShards, part = rem / kShards;
+	const uint32_t q = ray_queue_index(par, kind, shard);
+	const uint32_t total = a.cnt->n_ray[q];
+	const uint32_t i = part * kBlock + threadIdx.x;
+	WorkCount wc = {0, 0, 0};
+	if (i < total) {
+		const uint32_t slot = a.q_ray[(size_t)q * a.shard_cap + i];
+		const float4 r0 = a.ray0[slot], r1 = a.ray1[slot];
+		Ray ray = {mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y)};
+		HitRec h;
+		traverse_leafwise<false, COUNT, true>(a.tree, ray, FLT_MAX, lds_stack + threadIdx.x, depth, h, wc);
+		a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
+	}
+	if (COUNT)
+		count_flush(a.cnt, wc);
+}
+
 // The rays that need the division-based box test.  Any grid that is a multiple
 // of kShards works: the workgroups of a shard stride over its sub-queue.
 template <bool COUNT>
@@ -612,7 +642,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect_odd(const RenderArgs a, co
 
 // ------------------------------------------------------------------ shadow
 
-template <bool COUNT>
+template <bool COUNT, bool LEAFWISE>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_shadow(const RenderArgs a, const int depth)
 {
 	extern __shared__ uint32_t lds_stack[];
@@ -626,7 +656,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 		const float4 e0 = e[0], e1 = e[1], e2 = e[2];
 		Ray ray = {xyz(e0), xyz(e1)};
 		HitRec h;
-		traverse_dyn<true, COUNT>(a.tree, ray, e0.w, lds_stack + threadIdx.x, depth, h, wc);
+		if (LEAFWISE)
+			traverse_leafwise<true, COUNT>(a.tree, ray, e0.w, lds_stack + threadIdx.x, depth, h, wc);
+		else
+			traverse_dyn<true, COUNT>(a.tree, ray, e0.w, lds_stack + threadIdx.x, depth, h, wc);
 		if (h.prim < 0) {
 			// src/main.cpp:569: the light's contribution joins the path radiance
 			const uint32_t slot = __float_as_uint(e1.w);
@@ -1012,7 +1045,12 @@ void launch_sky_map(hipStream_t s, const TreeRef &tree, uint32_t n_pairs, const 
 void launch_intersect(hipStream_t s, const RenderArgs &a, int par, int depth, bool count)
 {
 	const unsigned blocks = kShards * ((a.shard_cap / kBlock + a.rays_per_lane - 1) / a.rays_per_lane) + kShards * (a.shard_cap / kBlock);
-	if (count)
+	const unsigned leafwise_blocks = 2 * kShards * (a.shard_cap / kBlock);
+	if (a.leafwise && count)
+		hipLaunchKernelGGL(k_intersect_leafwise<true>, dim3(leafwise_blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);
+	else if (a.leafwise)
+		hipLaunchKernelGGL(k_intersect_leafwise<false>, dim3(leafwise_blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);
+	else if (count)
 		hipLaunchKernelGGL(k_intersect<true>, dim3(blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);
 	else
 		hipLaunchKernelGGL(k_intersect<false>, dim3(blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);
@@ -1027,10 +1065,14 @@ void launch_intersect(hipStream_t s, const RenderArgs &a, int par, int depth, bo
 
 void launch_shadow(hipStream_t s, const RenderArgs &a, uint32_t bound, int depth, bool count)
 {
-	if (count)
-		hipLaunchKernelGGL(k_shadow<true>, dim3(blocks_for(bound)), dim3(kBlock), stack_bytes(depth), s, a, depth);
+	if (count && a.leafwise)
+		hipLaunchKernelGGL((k_shadow<true, true>), dim3(blocks_for(bound)), dim3(kBlock), stack_bytes(depth), s, a, depth);
+	else if (count)
+		hipLaunchKernelGGL((k_shadow<true, false>), dim3(blocks_for(bound)), dim3(kBlock), stack_bytes(depth), s, a, depth);
+	else if (a.leafwise)
+		hipLaunchKernelGGL((k_shadow<false, true>), dim3(blocks_for(bound)), dim3(kBlock), stack_bytes(depth), s, a, depth);
 	else
-		hipLaunchKernelGGL(k_shadow<false>, dim3(blocks_for(bound)), dim3(kBlock), stack_bytes(depth), s, a, depth);
+		hipLaunchKernelGGL((k_shadow<false, false>), dim3(blocks_for(bound)), dim3(kBlock), stack_bytes(depth), s, a, depth);
 }
 
 void launch_sum_blocks(hipStream_t s, const float4 *partial, const int32_t *pixels, uint32_t n_pad, uint32_t n_blocks,

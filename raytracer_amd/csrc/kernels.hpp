@@ -59,6 +59,7 @@ struct RenderArgs {
 	uint32_t *q_ray;               // closest-hit queues, [step parity][kind][shard][shard_cap] slot numbers
 	uint32_t shard_cap;            // entries per sub-queue, a multiple of the workgroup size
 	uint32_t rays_per_lane, refill_at;     // bounce-ray traversal: see traverse_pulling
+	uint32_t leafwise;             // the tree has long leaves: traverse_leafwise, one ray per lane (rays_per_lane = 1)
 	// occlusion queue, 3 per entry: (origin, limit) (direction, slot) (radiance, -)
 	float4 *shadow;
 	Counters *cnt;                 // this group's

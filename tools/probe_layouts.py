@@ -27,7 +27,7 @@ NAMES = {0: "production (64 B pair records, LDS stack, reciprocal box test, one 
 
 def main():
     reps = int(os.environ.get("REPS", "5"))
-    scene = rta.Scene.load(os.path.join(ROOT, "scenes", "dragon.txt")).build_bvh()
+    scene = rta.Scene.load(os.path.join(ROOT, "scenes", os.environ.get("SCENE", "dragon.txt"))).build_bvh()
     scene.set_render(1920, 1080, 1)
     ctx = rta.Context(0)
     ctx.upload(scene)

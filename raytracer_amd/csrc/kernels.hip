@@ -757,7 +757,7 @@ __global__ __launch_bounds__(kBlock) void k_fill_far(const RenderArgs a, const u
 //
 // k_cover_leaves marks the pixel-sized cells of the image plane (the frame and
 // kSkyBorder cells around it) that some leaf's rectangle, widened by the margin,
-// touches; one wave per (pair record, child).
+// touches; gridDim.y waves per (pair record, child).
 __global__ __launch_bounds__(kBlock) void k_cover_leaves(const TreeRef tree, const uint32_t n_pairs, const Projection pr,
                                                         const int map_w, const int map_h, uint8_t *cover)
 {
@@ -811,9 +811,11 @@ __global__ __launch_bounds__(kBlock) void k_cover_leaves(const TreeRef tree, con
 	const int cj0 = (int)(j0 < 0 ? 0 : j0), cj1 = (int)(j1 > map_h - 1 ? map_h - 1 : j1);
 	if (ci1 < ci0 || cj1 < cj0)
 		return;
-	const uint32_t ni = (uint32_t)(ci1 - ci0 + 1), nj = (uint32_t)(cj1 - cj0 + 1);
-	for (uint64_t idx = lane; idx < (uint64_t)ni * nj; idx += 64)
-		cover[(size_t)(cj0 + (int)(idx / ni)) * map_w + ci0 + (int)(idx % ni)] = 1;
+	// the rectangle's rows are dealt to the gridDim.y waves that look at this leaf (most leaves cover a
+	// few cells; a leaf that fills the frame would otherwise keep one wave busy for milliseconds)
+	for (int row = cj0 + (int)blockIdx.y; row <= cj1; row += (int)gridDim.y)
+		for (int col = ci0 + (int)lane; col <= ci1; col += 64)
+			cover[(size_t)row * map_w + col] = 1;
 }
 
 // The pixel filter moves a sample by .5 sqrt(-2 ln u1) pixels from the pixel's
@@ -1036,8 +1038,10 @@ void launch_sky_map(hipStream_t s, const TreeRef &tree, uint32_t n_pairs, const 
 {
 	const int map_w = (int)width + 2 * kSkyBorder, map_h = (int)height + 2 * kSkyBorder;
 	(void)hipMemsetAsync(cover, 0, (size_t)map_w * map_h, s);
-	hipLaunchKernelGGL(k_cover_leaves, dim3((2 * n_pairs + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, s, tree, n_pairs,
-	                   pr, map_w, map_h, cover);
+	// (a tree of a few leaves can have leaves that fill the frame; a tree of millions has waves enough)
+	const unsigned waves_per_leaf = n_pairs < (1u << 16) ? 32 : 1;
+	hipLaunchKernelGGL(k_cover_leaves, dim3((2 * n_pairs + kBlock / 64 - 1) / (kBlock / 64), waves_per_leaf), dim3(kBlock), 0, s,
+	                   tree, n_pairs, pr, map_w, map_h, cover);
 	hipLaunchKernelGGL(k_sky_map, dim3(blocks_for((uint64_t)width * height)), dim3(kBlock), 0, s, cover, (int)width,
 	                   (int)height, sky_map);
 }

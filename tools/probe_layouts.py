@@ -46,6 +46,12 @@ def main():
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     bounce = np.tile(np.concatenate([p, d], axis=1).astype(np.float32), (8, 1))
     sets = {"camera rays 1080p": prim, "bounce rays x8": bounce}
+    if os.environ.get("OCTANT"):
+        # the same bounce rays, runs of OCTANT consecutive ones ordered by direction octant
+        run = int(os.environ["OCTANT"])
+        octant = (bounce[:, 3] < 0).astype(np.int64) | ((bounce[:, 4] < 0).astype(np.int64) << 1) | ((bounce[:, 5] < 0).astype(np.int64) << 2)
+        key = (np.arange(len(bounce)) // run) * 8 + octant
+        sets[f"bounce x8, octants/{run}"] = bounce[np.argsort(key, kind="stable")]
     for label, rr in sets.items():
         rt = torch.from_numpy(np.ascontiguousarray(rr)).to(dev)
         n = rr.shape[0]

@@ -20,7 +20,13 @@
  *  - a context is bound to ONE GPU and is driven by one host thread at a time;
  *    multi-GPU jobs use one process (and one context) per GPU;
  *  - the compute entry points fail with RTA_E_NO_DEVICE when no GPU is
- *    present; there is no CPU fallback.
+ *    present; there is no CPU fallback;
+ *  - all device work runs on the context's own non-blocking HIP streams and
+ *    every compute call returns only after that work has finished.  RTA_MEM_DEVICE
+ *    buffers are NOT ordered against the caller's streams: whatever produces an
+ *    input (rays, tmax, accum) must have completed before the call - synchronise
+ *    the producing stream, or make rta_stream() wait on an event of it - and
+ *    outputs may be read from any stream once the call has returned.
  */
 #ifndef RAYTRACER_AMD_H
 #define RAYTRACER_AMD_H
@@ -70,7 +76,10 @@ void rta_scene_free(rta_scene *scene);
 /* Replaces BuildBVH + UpdateBounds + the light re-link (src/main.cpp:133-248,
  * 617-622): midpoint split on the longest axis, swap partition, children at
  * consecutive indices; permutes the scene's primitives exactly as the reference
- * permutes `objects`. */
+ * permutes `objects`.  Like the reference's, the builder bounds only the number
+ * of pending second children (64, src/main.cpp:182-185), not the depth of the
+ * tree; a tree deeper than 64 levels (degenerate, right-leaning input) can be
+ * built and described but not uploaded: rta_upload_scene answers RTA_E_LIMIT. */
 int rta_scene_build_bvh(rta_scene *scene);
 
 typedef struct {
@@ -105,8 +114,9 @@ typedef struct {
 } rta_scene_desc;
 
 int rta_scene_describe(const rta_scene *scene, rta_scene_desc *out);
-/* The checks rta_upload_scene applies (index ranges, tree shape, depth <= 64,
- * no primitive in two leaves), without a GPU.  err receives what is wrong. */
+/* The checks rta_upload_scene applies (index ranges, tree shape, no primitive
+ * in two leaves: RTA_E_INVALID; depth <= 64, the reference's traversal stack,
+ * src/main.cpp:339: RTA_E_LIMIT), without a GPU.  err receives what is wrong. */
 int rta_validate_scene(const rta_scene_desc *desc, char *err, size_t errlen);
 /* BVH-order position -> position in the scene file (the build's permutation). */
 int rta_scene_permutation(const rta_scene *scene, const int32_t **perm, int32_t *n);
@@ -145,9 +155,13 @@ const char *rta_last_error(const rta_context *ctx);
  * the time of the build kernels, 0 when the host builder ran. */
 int rta_scene_build_bvh_device(rta_context *ctx, rta_scene *scene, float *device_ms);
 
-/* Validates the description (index ranges, tree shape, depth <= 64, every
- * primitive in exactly one leaf) and builds the device layouts.  Replaces the
- * hand-over of `Scene`/`BVHTree` to the render loop (src/main.cpp:607-615). */
+/* Validates the description (index ranges, tree shape, every primitive in at
+ * most one leaf; RTA_E_LIMIT for a tree deeper than 64 levels) and builds the
+ * device layouts.  Replaces the hand-over of `Scene`/`BVHTree` to the render
+ * loop (src/main.cpp:607-615).  A node whose box has min > max on some axis is
+ * legal (the reference would take it as it is); such a tree is traversed with
+ * the division-based box test only, which picks the planes by the direction's
+ * sign bit exactly as src/main.cpp:303-330 does. */
 int rta_upload_scene(rta_context *ctx, const rta_scene_desc *desc);
 
 typedef struct {
@@ -187,7 +201,7 @@ typedef struct {
 } rta_render_params;
 
 enum {
-	RTA_RENDER_TIME_KERNELS = 1,   /* bracket every intersect launch with HIP events (stats.intersect_ms) */
+	RTA_RENDER_TIME_KERNELS = 1,   /* bracket every advance, shadow and intersect launch with HIP events (stats.*_ms) */
 	RTA_RENDER_COUNT_WORK = 2,     /* count node visits / primitive tests (slower kernels) */
 	RTA_RENDER_SMALL_PASSES = 4    /* hold as few sample blocks in memory at a time as possible (see rta_render) */
 };
@@ -201,7 +215,10 @@ typedef struct {
 	uint64_t intersect_launches, shadow_launches;
 	uint64_t early_rays;                    /* of `rays`: camera rays that provably miss every leaf's box (the
 	                                         * reference's NearestHit would test no primitive), answered where
-	                                         * they are generated and never queued for traversal */
+	                                         * they are generated and never queued for traversal; rays - early_rays
+	                                         * is the number of closest-hit queries that walked the tree */
+	double advance_ms;                      /* RTA_RENDER_TIME_KERNELS only: summed durations of the advance launches */
+	uint64_t advance_launches;
 } rta_stats;
 
 /* The render loop.  Replaces src/main.cpp:657-714 (row loop, per-sample ray

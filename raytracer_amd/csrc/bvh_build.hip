@@ -509,14 +509,18 @@ std::string device_build_bvh(hipStream_t s, int32_t n, const int32_t *prim_type,
 
 	BUILD_TRY(hipMemcpyAsync(d_type, prim_type, (size_t)n * 4, hipMemcpyHostToDevice, s));
 	BUILD_TRY(hipMemcpyAsync(d_geom, geom, (size_t)n * 36, hipMemcpyHostToDevice, s));
-	hipEvent_t ev0, ev1;
-	BUILD_TRY(hipEventCreate(&ev0));
-	BUILD_TRY(hipEventCreate(&ev1));
-	auto drop_events = [&] {
-		(void)hipEventDestroy(ev0);
-		(void)hipEventDestroy(ev1);
-	};
-	(void)hipEventRecord(ev0, s);
+	// destroyed on every way out of this function
+	struct Events {
+		hipEvent_t a = nullptr, b = nullptr;
+		~Events()
+		{
+			if (a) (void)hipEventDestroy(a);
+			if (b) (void)hipEventDestroy(b);
+		}
+	} ev;
+	BUILD_TRY(hipEventCreate(&ev.a));
+	BUILD_TRY(hipEventCreate(&ev.b));
+	(void)hipEventRecord(ev.a, s);
 
 	hipLaunchKernelGGL(k_init_root, dim3(1), dim3(1), 0, s, n, nd, counters, counters + 1);
 	hipLaunchKernelGGL(k_prepare, dim3(grid_for(n)), dim3(kThreads), 0, s, n, d_type, d_geom, plo, phi, cen, order[0],
@@ -543,16 +547,13 @@ std::string device_build_bvh(hipStream_t s, int32_t n, const int32_t *prim_type,
 		BUILD_TRY(hipMemcpyAsync(host_counters, counters, 8, hipMemcpyDeviceToHost, s));
 		BUILD_TRY(hipStreamSynchronize(s));
 		if (host_counters[1]) {
-			drop_events();
 			unsupported = true;
 			return "non-finite primitive coordinates";
 		}
 		begin = end;
 		end = host_counters[0];
-		if ((size_t)end > cap) {
-			drop_events();
+		if ((size_t)end > cap)
 			return "node count exceeds 2n";
-		}
 	}
 	const int32_t total = end;
 	const int levels = (int)level_begin.size() - 1;
@@ -563,7 +564,7 @@ std::string device_build_bvh(hipStream_t s, int32_t n, const int32_t *prim_type,
 		hipLaunchKernelGGL(k_number, dim3(grid_for(level_begin[l + 1] - level_begin[l])), dim3(kThreads), 0, s,
 		                   level_begin[l], level_begin[l + 1], nd);
 	hipLaunchKernelGGL(k_emit, dim3(grid_for(total)), dim3(kThreads), 0, s, total, nd, out_bounds, out_index, out_count);
-	(void)hipEventRecord(ev1, s);
+	(void)hipEventRecord(ev.b, s);
 	BUILD_TRY(hipGetLastError());
 
 	out.perm.resize(n);
@@ -576,8 +577,7 @@ std::string device_build_bvh(hipStream_t s, int32_t n, const int32_t *prim_type,
 	BUILD_TRY(hipMemcpyAsync(out.node_count.data(), out_count, (size_t)total * 4, hipMemcpyDeviceToHost, s));
 	BUILD_TRY(hipStreamSynchronize(s));
 	float ms = 0;
-	(void)hipEventElapsedTime(&ms, ev0, ev1);
-	drop_events();
+	(void)hipEventElapsedTime(&ms, ev.a, ev.b);
 	out.device_ms = ms;
 	out.levels = levels;
 #undef BUILD_TRY

@@ -13,13 +13,11 @@
 #include <vector>
 
 #include "bvh_build.hpp"
+#include "context.hpp"
 #include "host_scene.hpp"
 #include "kernels.hpp"
 
 namespace rta {
-
-void set_global_error(const std::string &text);      // api.cpp
-const char *get_global_error();
 
 namespace {
 
@@ -27,86 +25,12 @@ constexpr uint32_t kLeaf = 0x80000000u;
 constexpr uint32_t kSphereFlag = 1u, kLastFlag = 2u;
 constexpr int kMaxDepth = 64;             // the reference's traversal stack (src/main.cpp:339)
 constexpr int kTile = 8;                  // pixels per tile side; 64 pixels = one wave64
-constexpr int kMaxGroups = 8;             // slot groups = concurrent HIP streams per render
-
-struct DeviceBuffer {
-	void *ptr = nullptr;
-	size_t bytes = 0;
-
-	~DeviceBuffer() { release(); }
-	void release()
-	{
-		if (ptr)
-			(void)hipFree(ptr);
-		ptr = nullptr;
-		bytes = 0;
-	}
-	// grow-only
-	hipError_t reserve(size_t want)
-	{
-		if (want <= bytes)
-			return hipSuccess;
-		release();
-		hipError_t e = hipMalloc(&ptr, want);
-		if (e == hipSuccess)
-			bytes = want;
-		return e;
-	}
-	template <typename T>
-	T *as() const { return static_cast<T *>(ptr); }
-};
 
 }  // namespace
 
 }  // namespace rta
 
 using namespace rta;
-
-struct rta_context {
-	int device = -1;
-	hipStream_t stream = nullptr;         // group 0 and everything that is not a wavefront step
-	hipStream_t extra[kMaxGroups - 1] = {};  // the other slot groups
-	std::string error;
-
-	// scene
-	bool have_scene = false;
-	DeviceBuffer pairs, prims, shade_prims, materials, lights, ref_nodes;
-	DeviceBuffer soa_nodes;      // variant 5 only, made from `pairs` on first use
-	uint32_t n_pairs = 0;
-	bool have_soa = false;
-	uint32_t root_ref = 0;
-	bool tame = false;           // box coordinates allow the reciprocal slab test (traverse.hpp)
-	bool box_known = false;      // `box` is the box around the root's two children
-	float box[6] = {0, 0, 0, 0, 0, 0};
-	int stack_depth = 1;
-	int32_t n_prims = 0, n_lights = 0;
-
-	// wavefront workspace
-	DeviceBuffer ray0, ray1, hit, thr, col, rng, acc, meta, q_ray, shadow, partial, pixels, frame, bgr, counters;
-	DeviceBuffer part_weights, part_order;
-	DeviceBuffer cover, sky_map;         // see k_sky_map
-	DeviceBuffer ray_order;              // see tracing_order
-	DeviceBuffer io_a, io_b, io_c;       // staging for host-pointer calls
-	Counters *host_counters = nullptr;    // pinned, kMaxGroups entries
-
-	int fail(int code, const std::string &text)
-	{
-		error = text;
-		return code;
-	}
-	int hip_fail(hipError_t e, const char *what)
-	{
-		error = std::string(what) + ": " + hipGetErrorString(e);
-		return RTA_E_DEVICE;
-	}
-};
-
-#define HIP_TRY(ctx, call)                                                  \
-	do {                                                                    \
-		hipError_t e__ = (call);                                            \
-		if (e__ != hipSuccess)                                              \
-			return (ctx)->hip_fail(e__, #call);                             \
-	} while (0)
 
 extern "C" {
 
@@ -183,6 +107,23 @@ void *rta_stream(rta_context *ctx) { return ctx ? (void *)ctx->stream : nullptr;
 
 // ------------------------------------------------------------------ upload
 
+namespace rta {
+
+TreeRef tree_of(const rta_context *ctx)
+{
+	TreeRef t;
+	t.pairs = ctx->pairs.as<const float4>();
+	t.prims = ctx->prims.as<const float4>();
+	t.root = ctx->root_ref;
+	t.tame = ctx->tame ? 1u : 0u;
+	t.box_known = ctx->box_known ? 1u : 0u;
+	memcpy(t.box_lo, ctx->box, 12);
+	memcpy(t.box_hi, ctx->box + 3, 12);
+	return t;
+}
+
+}  // namespace rta
+
 namespace {
 
 struct Flattened {
@@ -193,6 +134,7 @@ struct Flattened {
 	bool tame = true;
 	bool box_known = false;            // `box`: lo xyz, hi xyz around the root's two children
 	float box[6] = {0, 0, 0, 0, 0, 0};
+	bool over_limit = false;           // the problem reported is a size limit, not a malformed description
 };
 
 inline float as_float(uint32_t u)
@@ -273,8 +215,11 @@ std::string flatten(const rta_scene_desc &d, Flattened &out)
 			todo.push_back({idx, it.depth + 1});
 		}
 	}
-	if (max_depth > kMaxDepth)
-		return "tree depth " + std::to_string(max_depth) + " exceeds the traversal stack of " + std::to_string(kMaxDepth);
+	if (max_depth > kMaxDepth) {
+		out.over_limit = true;
+		return "tree depth " + std::to_string(max_depth) + " exceeds the traversal stack of " + std::to_string(kMaxDepth) +
+		       " entries (the reference's own, src/main.cpp:339)";
+	}
 	// primitives outside every leaf are unreachable, which is legal for a
 	// caller-made tree but would leave their records without a leaf terminator
 	out.depth = std::max(max_depth, 1);
@@ -289,6 +234,15 @@ std::string flatten(const rta_scene_desc &d, Flattened &out)
 	for (size_t k = 0; k < (size_t)d.n_nodes * 6; k++) {
 		const float m = std::fabs(d.node_bounds[k]);
 		if (!(m == 0.f || (m >= 0x1p-78f && m <= 0x1p40f)))
+			out.tame = false;
+	}
+	// The reciprocal test takes the smaller quotient of an axis as the entry and
+	// the larger as the exit, which equals the reference's selection by the
+	// direction's sign bit only while min <= max.  A caller-made tree with an
+	// inverted box is traversed with the division-based test throughout.
+	for (int32_t k = 0; k < d.n_nodes && out.tame; k++) {
+		const float *b = d.node_bounds + (size_t)k * 6;
+		if (!(b[0] <= b[3] && b[1] <= b[4] && b[2] <= b[5]))
 			out.tame = false;
 	}
 	// The box around the root's children (the root's own box is never tested,
@@ -368,18 +322,6 @@ int upload_vec(rta_context *ctx, DeviceBuffer &buf, const std::vector<T> &v)
 	return RTA_OK;
 }
 
-TreeRef tree_of(const rta_context *ctx)
-{
-	TreeRef t;
-	t.pairs = ctx->pairs.as<const float4>();
-	t.prims = ctx->prims.as<const float4>();
-	t.root = ctx->root_ref;
-	t.tame = ctx->tame ? 1u : 0u;
-	t.box_known = ctx->box_known ? 1u : 0u;
-	memcpy(t.box_lo, ctx->box, 12);
-	memcpy(t.box_hi, ctx->box + 3, 12);
-	return t;
-}
 
 // Owned pixels in walk order: tiles row-major, pixels row-major inside a tile.
 // With `padded`, every tile contributes exactly 64 entries and the positions
@@ -417,7 +359,7 @@ int rta_validate_scene(const rta_scene_desc *desc, char *err, size_t errlen)
 	set_global_error("invalid scene: " + problem);
 	if (err && errlen)
 		snprintf(err, errlen, "%s", problem.c_str());
-	return RTA_E_INVALID;
+	return f.over_limit ? RTA_E_LIMIT : RTA_E_INVALID;
 }
 
 int rta_scene_build_bvh_device(rta_context *ctx, rta_scene *scene, float *device_ms)
@@ -466,7 +408,7 @@ int rta_upload_scene(rta_context *ctx, const rta_scene_desc *desc)
 	Flattened f;
 	std::string problem = flatten(*desc, f);
 	if (!problem.empty())
-		return ctx->fail(RTA_E_INVALID, "invalid scene: " + problem);
+		return ctx->fail(f.over_limit ? RTA_E_LIMIT : RTA_E_INVALID, "invalid scene: " + problem);
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	ctx->have_scene = false;
 	int rc;
@@ -892,15 +834,12 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	hipStream_t s = ctx->stream;
 
 	hipEvent_t ev_begin = nullptr, ev_mid = nullptr, ev_end = nullptr;
-	HIP_TRY(ctx, hipEventCreate(&ev_begin));
-	HIP_TRY(ctx, hipEventCreate(&ev_mid));
-	HIP_TRY(ctx, hipEventCreate(&ev_end));
-	std::vector<hipEvent_t> ev_pool;        // begin/end pairs around timed launches, then the per-group end marks
-	std::vector<int> ev_kind;               // 0 intersect, 1 shadow
+	std::vector<hipEvent_t> ev_pool;        // begin/end pairs around timed launches
+	std::vector<int> ev_kind;               // 0 intersect, 1 shadow, 2 advance
 	auto cleanup = [&]() {
-		(void)hipEventDestroy(ev_begin);
-		(void)hipEventDestroy(ev_mid);
-		(void)hipEventDestroy(ev_end);
+		for (hipEvent_t e : {ev_begin, ev_mid, ev_end})
+			if (e)
+				(void)hipEventDestroy(e);
 		for (hipEvent_t e : ev_pool)
 			(void)hipEventDestroy(e);
 	};
@@ -913,6 +852,9 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		}                                                    \
 	} while (0)
 
+	HIP_TRY_R(hipEventCreate(&ev_begin));
+	HIP_TRY_R(hipEventCreate(&ev_mid));
+	HIP_TRY_R(hipEventCreate(&ev_end));
 	if (n_pad)
 		HIP_TRY_R(hipMemcpyAsync(ctx->pixels.ptr, px.data(), (size_t)n_pad * 4, hipMemcpyHostToDevice, s));
 	HIP_TRY_R(hipEventRecord(ev_begin, s));
@@ -1011,6 +953,13 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 			ga[g].group = (uint32_t)g;
 			ga[g].n_groups = (uint32_t)groups;
 			ga[g].streams_per_part = (64 / lane_blocks) * ((end_block - first_block + run_blocks - 1) / run_blocks);
+			// Counters::next_item is bumped by every waiting wave even once the list is dry
+			// (at most once per lane and pass), so the list's length plus the pool must
+			// stay clear of 2^32
+			if ((uint64_t)parts_here * ga[g].streams_per_part + n_slots >= 0xffffffffull) {
+				cleanup();
+				return ctx->fail(RTA_E_LIMIT, "pixels x sample blocks exceeds 2^32; raise samples_per_stream");
+			}
 			ga[g].n_streams = parts_here * ga[g].streams_per_part;
 			ga[g].grab_at = grab_at;
 			launch_init_slots(gs[g], ga[g], group_slots);
@@ -1023,7 +972,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 					const int par = (int)(steps & 1);
 					// advance queues the step's rays; shadow comes before intersect, whose
 					// first workgroup empties the occlusion queue for the next step
-					launch_advance(gs[g], a, par);
+					HIP_TRY_R(timed(gs[g], 2, [&] { launch_advance(gs[g], a, par); }));
 					if (lights)
 						HIP_TRY_R(timed(gs[g], 1, [&] { launch_shadow(gs[g], a, group_slots, ctx->stack_depth, count_work); }));
 					HIP_TRY_R(timed(gs[g], 0, [&] { launch_intersect(gs[g], a, par, ctx->stack_depth, count_work); }));
@@ -1088,6 +1037,9 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		if (ev_kind[k] == 0) {
 			st.intersect_ms += t;
 			st.intersect_launches++;
+		} else if (ev_kind[k] == 2) {
+			st.advance_ms += t;
+			st.advance_launches++;
 		} else {
 			st.shadow_ms += t;
 			st.shadow_launches++;

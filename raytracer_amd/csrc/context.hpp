@@ -1,0 +1,99 @@
+// The device context behind rta_context: the GPU copies of a scene, the
+// wavefront workspace and the streams.  Shared by the translation units that
+// implement the device half of include/raytracer_amd.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "kernels.hpp"
+
+namespace rta {
+
+void set_global_error(const std::string &text);      // api.cpp
+const char *get_global_error();
+
+constexpr int kMaxGroups = 8;             // slot groups = concurrent HIP streams per render
+
+struct DeviceBuffer {
+	void *ptr = nullptr;
+	size_t bytes = 0;
+
+	~DeviceBuffer() { release(); }
+	void release()
+	{
+		if (ptr)
+			(void)hipFree(ptr);
+		ptr = nullptr;
+		bytes = 0;
+	}
+	// grow-only
+	hipError_t reserve(size_t want)
+	{
+		if (want <= bytes)
+			return hipSuccess;
+		release();
+		hipError_t e = hipMalloc(&ptr, want);
+		if (e == hipSuccess)
+			bytes = want;
+		return e;
+	}
+	template <typename T>
+	T *as() const { return static_cast<T *>(ptr); }
+};
+
+}  // namespace rta
+
+struct rta_context {
+	int device = -1;
+	hipStream_t stream = nullptr;         // group 0 and everything that is not a wavefront step
+	hipStream_t extra[rta::kMaxGroups - 1] = {};  // the other slot groups
+	std::string error;
+
+	// scene
+	bool have_scene = false;
+	rta::DeviceBuffer pairs, prims, shade_prims, materials, lights, ref_nodes;
+	rta::DeviceBuffer soa_nodes;      // variant 5 only, made from `pairs` on first use
+	uint32_t n_pairs = 0;
+	bool have_soa = false;
+	uint32_t root_ref = 0;
+	bool tame = false;           // box coordinates allow the reciprocal slab test (traverse.hpp)
+	bool box_known = false;      // `box` is the box around the root's two children
+	float box[6] = {0, 0, 0, 0, 0, 0};
+	int stack_depth = 1;
+	int32_t n_prims = 0, n_lights = 0;
+
+	// wavefront workspace
+	rta::DeviceBuffer ray0, ray1, hit, thr, col, rng, acc, meta, q_ray, shadow, partial, pixels, frame, bgr, counters;
+	rta::DeviceBuffer part_weights, part_order;
+	rta::DeviceBuffer cover, sky_map;         // see k_sky_map
+	rta::DeviceBuffer ray_order;              // see tracing_order
+	rta::DeviceBuffer io_a, io_b, io_c;       // staging for host-pointer calls
+	rta::Counters *host_counters = nullptr;   // pinned, kMaxGroups entries
+
+	int fail(int code, const std::string &text)
+	{
+		error = text;
+		return code;
+	}
+	int hip_fail(hipError_t e, const char *what)
+	{
+		error = std::string(what) + ": " + hipGetErrorString(e);
+		return RTA_E_DEVICE;
+	}
+};
+
+#define HIP_TRY(ctx, call)                                                  \
+	do {                                                                    \
+		hipError_t e__ = (call);                                            \
+		if (e__ != hipSuccess)                                              \
+			return (ctx)->hip_fail(e__, #call);                             \
+	} while (0)
+
+namespace rta {
+
+// the uploaded tree as the kernels take it
+TreeRef tree_of(const rta_context *ctx);
+
+}  // namespace rta

@@ -649,7 +649,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
 	const uint32_t n = a.cnt->n_shadow;
 	if (i == 0)
-		a.cnt->shadow_rays += n;
+		atomicAdd(&a.cnt->shadow_rays, (unsigned long long)n);
 	WorkCount wc = {0, 0, 0};
 	if (i < n) {
 		const float4 *e = a.shadow + 3 * (size_t)i;

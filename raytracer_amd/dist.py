@@ -30,7 +30,13 @@ class ShardGather:
             return frame
         flat = frame.view(-1, 3)
         self.send[: self.counts[self.rank]] = flat[self.mine]
-        dist.all_gather_into_tensor(self.recv.view(-1, 3), self.send)
+        if self.send.is_cuda and dist.get_backend() == "gloo":
+            # gloo gathers host tensors only (rehearsals of the N > 1 path on one GPU)
+            recv = torch.empty(self.recv.shape, dtype=self.recv.dtype)
+            dist.all_gather_into_tensor(recv.view(-1, 3), self.send.cpu())
+            self.recv.copy_(recv)
+        else:
+            dist.all_gather_into_tensor(self.recv.view(-1, 3), self.send)
         parts = [self.recv[r, : self.counts[r]] for r in range(self.world)]
         flat[self.everyone] = torch.cat(parts)
         return frame

@@ -102,7 +102,7 @@ def ray_fixture(name):
 def main():
     if not orc.have_ref():
         sys.exit("build the reference first: make -C oracle ref")
-    out = {"scenes": {}, "renders": {}, "small_renders": {}, "kat": {}, "parse_errors": {}}
+    out = {"scenes": {}, "renders": {}, "small_renders": {}, "tolerance_renders": {}, "kat": {}, "parse_errors": {}}
 
     for name in SCENES:
         info, nodes = ray_fixture(name)
@@ -146,6 +146,16 @@ def main():
         with open(os.path.join(HERE, fname), "wb") as f:
             f.write(data)
         out["small_renders"][fname] = {"scene": scene, "width": w, "height": h, "samples": spp, "md5": md5}
+
+    # renders with enough samples for a stated-tolerance comparison of images rendered from
+    # other random streams (the reference's own streams are per image row)
+    out["tolerance_renders"] = {}
+    for scene, (w, h, spp) in {"cornell_box.txt": (200, 200, 256), "dragon.txt": (200, 200, 256)}.items():
+        md5, data = ref_binary_render(orc.scene_variant(scene, w, h, spp))
+        fname = f"ref_{scene.split('.')[0]}_{w}x{h}x{spp}.bmp"
+        with open(os.path.join(HERE, fname), "wb") as f:
+            f.write(data)
+        out["tolerance_renders"][fname] = {"scene": scene, "width": w, "height": h, "samples": spp, "md5": md5}
 
     # random numbers
     st = C.c_uint32(69420)

@@ -1,0 +1,313 @@
+"""The benchmark configurations at their full sizes, through the C ABI, against
+the CPU checker: whole frames bit for bit, the 10 M-triangle intersect-only
+workload on a strided subset plus a checksum, the 4K frame as 8 shards, and the
+stated-tolerance comparison with images rendered by the reference binary.
+
+Each test says what it costs on the GPU box's 16 host threads; the checker is
+the slow side everywhere.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import orc
+import rays as raygen
+import raytracer_amd as rta
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def load_pair(name, w, h, spp):
+    path = f"{orc.SCENES}/{name}"
+    osc = orc.Scene.load(path).build_bvh().set_render(w, h, spp)
+    psc = rta.Scene.load(path).build_bvh().set_render(w, h, spp)
+    return osc, psc
+
+
+@pytest.mark.parametrize("name,spp,sps", [("dragon.txt", 1024, 16), ("cornell_box.txt", 256, 16)])
+def test_benchmark_frames_bit_exact(gpu, name, spp, sps):
+    """dragon.txt 1920x1080 x 1024 spp and cornell_box.txt 1920x1080 x 256 spp,
+    the two single-GPU render configurations, at the benchmark's own sample
+    counts and samples per stream: every pixel's radiance bits, the ray counts
+    and the B,G,R bytes equal the checker's (about 30 s and 20 s of checker
+    time).  Every sample that the GPU path decides on the image plane is
+    computed in full by the checker."""
+    osc, psc = load_pair(name, 1920, 1080, spp)
+    gpu.upload(psc)
+    bgr, acc, st = gpu.render_scene(psc, seed=69420, samples_per_stream=sps)
+    want_bgr, want_acc, cn = osc.render(orc.RNG_STREAM, orc.MATH_PM, seed=69420, samples_per_stream=sps)
+    assert st["samples"] == cn["samples"] == 1920 * 1080 * spp
+    assert st["rays"] == cn["rays"] and st["shadow_rays"] == cn["shadow_rays"]
+    differ = (bits(acc) != bits(want_acc)).any(axis=2)
+    assert not differ.any(), f"{int(differ.sum())} pixels differ in radiance bits"
+    assert np.array_equal(bgr, want_bgr)
+
+
+def test_dragon_4k_in_eight_shards(gpu):
+    """dragon.txt 3840x2160 split into 8 interleaved tile shards, rendered one
+    after the other on this GPU as 8 ranks would render them side by side:
+    assembled, the shards are the checker's frame bit for bit (16 spp here, a
+    sample count the checker finishes in seconds), no shard writes a pixel it
+    does not own, and the ray counts add up.  Two- and four-way splits give
+    the same frame."""
+    w, h, spp, sps = 3840, 2160, 16, 8
+    osc, psc = load_pair("dragon.txt", w, h, spp)
+    gpu.upload(psc)
+    want_bgr, want_acc, cn = osc.render(orc.RNG_STREAM, orc.MATH_PM, seed=69420, samples_per_stream=sps)
+    for n in (8, 4, 2):
+        acc = np.zeros((h, w, 3), np.float32)
+        bgr = np.zeros((h, w, 3), np.uint8)
+        rays = samples = 0
+        for r in range(n):
+            b, a, st = gpu.render_scene(psc, seed=69420, samples_per_stream=sps, shard_index=r, shard_count=n)
+            if n == 8:
+                px = rta.shard_pixels(w, h, r, n)
+                untouched = np.ones(w * h, bool)
+                untouched[px] = False
+                assert not a.reshape(-1, 3)[untouched].any(), "a shard wrote pixels it does not own"
+                assert st["samples"] == len(px) * spp
+            acc += a
+            bgr += b
+            rays += st["rays"]
+            samples += st["samples"]
+        assert samples == w * h * spp and rays == cn["rays"], n
+        assert np.array_equal(bits(acc), bits(want_acc)), n
+        assert np.array_equal(bgr, want_bgr), n
+
+
+def test_dragon_4k_4096spp_shard_properties(gpu):
+    """One of the 8 shards of dragon.txt 3840x2160 x 4096 spp at full sample
+    count (4.2 G samples on this GPU; the checker would need minutes, so
+    size-independent properties stand in): the shard's sample count, rays per
+    sample in the reference's range, pixels that only see the sky sum to
+    exactly 4096 x sky (128 block sums of 32 samples) and resolve to the sky's
+    bytes, and the shard agrees with the same pixels of a 64-spp render from
+    other streams within Monte-Carlo noise."""
+    w, h, spp = 3840, 2160, 4096
+    _, psc = load_pair("dragon.txt", w, h, spp)
+    gpu.upload(psc)
+    dev = torch.device("cuda", 0)
+    frame = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
+    out = torch.zeros((h, w, 3), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    s = psc.settings
+    p = rta.RenderParams(width=w, height=h, samples=spp, exposure=s.exposure, seed=69420, samples_per_stream=32,
+                         shard_index=3, shard_count=8, out_mem=rta.MEM_DEVICE)
+    p.sky[:] = list(s.sky)
+    st = gpu.render_device(psc.camera(), p, frame.data_ptr(), out.data_ptr())
+    px = torch.from_numpy(rta.shard_pixels(w, h, 3, 8).astype(np.int64)).to(dev)
+    assert st["samples"] == len(px) * spp
+    assert 1.15 < st["rays"] / st["samples"] < 1.26
+    mine = frame.view(-1, 3)[px]
+    sky = torch.tensor([0.5 * spp, 0.5 * spp, 1.0 * spp], device=dev)
+    pure = (mine == sky).all(dim=1)
+    assert 0.86 < pure.float().mean().item() < 0.90
+    assert (out.view(-1, 3)[px][pure] == torch.tensor([187, 156, 156], dtype=torch.uint8, device=dev)).all()
+    other = torch.ones(w * h, dtype=torch.bool, device=dev)
+    other[px] = False
+    assert not frame.view(-1, 3)[other].any(), "the shard wrote pixels it does not own"
+    # the same pixels from different streams at 64 spp
+    psc.set_render(w, h, 64)
+    low = torch.zeros((h, w, 3), dtype=torch.uint8, device=dev)
+    p2 = rta.RenderParams(width=w, height=h, samples=64, exposure=s.exposure, seed=7, samples_per_stream=32,
+                          shard_index=3, shard_count=8, out_mem=rta.MEM_DEVICE)
+    p2.sky[:] = list(s.sky)
+    gpu.render_device(psc.camera(), p2, None, low.data_ptr())
+    d = low.view(-1, 3)[px].double() - out.view(-1, 3)[px].double()
+    rmse = float(torch.sqrt((d * d).mean()))
+    assert rmse < 1.2, rmse                # noise of the 64-spp frame: ~0.7 expected (3.6 / sqrt(64 / 25) on the non-sky tenth)
+    assert abs(float(d.mean())) < 0.05
+
+
+def _soup(n, seed=1):
+    """Centres uniform in [-1,1]^3, vertices = centre + uniform [-0.01,0.01]^3."""
+    rng = np.random.default_rng(seed)
+    out = np.empty((n, 9), np.float32)
+    step = 1 << 20
+    for a in range(0, n, step):
+        m = min(step, n - a)
+        c = rng.uniform(-1, 1, (m, 1, 3)).astype(np.float32)
+        out[a:a + m] = (c + rng.uniform(-0.01, 0.01, (m, 3, 3)).astype(np.float32)).reshape(m, 9)
+    return out
+
+
+def _coherent(side, dev):
+    """A side x side pinhole grid from (-3, 0, 0) looking at the origin, 40 degrees wide."""
+    half = float(np.tan(np.radians(20.0)))
+    t = (torch.arange(side, device=dev, dtype=torch.float32) + 0.5) / side * 2 - 1
+    y = (t * half).view(1, side).expand(side, side)
+    z = (-t * half).view(side, 1).expand(side, side)
+    d = torch.stack([torch.ones_like(y), y, z], dim=-1).reshape(-1, 3)
+    d = d / d.norm(dim=1, keepdim=True)
+    o = torch.tensor([-3.0, 0.0, 0.0], device=dev).expand_as(d)
+    return torch.cat([o, d], dim=1).contiguous()
+
+
+def _incoherent(n, dev, seed=2):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    o = torch.rand((n, 3), device=dev, generator=g) * 2 - 1
+    d = torch.randn((n, 3), device=dev, generator=g)
+    d = d / d.norm(dim=1, keepdim=True)
+    return torch.cat([o, d], dim=1).contiguous()
+
+
+def test_ten_million_triangle_soup(gpu):
+    """The intersect-only configuration at full size: 10 M random triangles, the
+    reference builder's tree built on the GPU and compared bit for bit with the
+    CHECKER's tree, 64 Mi coherent + 64 Mi incoherent rays resident in HBM.  A
+    strided subset of 1 Mi rays per batch is traced by the checker and must agree
+    in primitive index and t, u, v bits; a checksum over all indices of a batch
+    must be the same when the batch is traced again in two halves (the halves take
+    another tracing order)."""
+    n_tri, n_rays, n_check = 10_000_000, 64 * 1024 * 1024, 1 << 20
+    dev = torch.device("cuda", 0)
+    soup = _soup(n_tri)
+    scene = rta.Scene.from_triangles(soup)
+    assert scene.build_bvh_on(gpu) > 0
+    checker = orc.Scene.from_triangles(soup).build_bvh()
+    del soup
+    # the device-built tree is the checker's tree: nodes and primitive order
+    a = scene.arrays()
+    nodes, objs = checker.nodes(), checker.objects()
+    assert len(nodes) == len(a["node_index"])
+    assert np.array_equal(a["node_index"], nodes["index"]) and np.array_equal(a["node_count"], nodes["count"])
+    assert np.array_equal(bits(a["node_bounds"][:, 0:3]), bits(nodes["lo"]))
+    assert np.array_equal(bits(a["node_bounds"][:, 3:6]), bits(nodes["hi"]))
+    assert np.array_equal(bits(a["prim_geom"]), bits(objs["geom"][:, 0:9]))
+    del a, nodes, objs
+    gpu.upload(scene)
+    side = int(round(n_rays ** 0.5))
+    weights = torch.arange(n_rays, device=dev) % 1000003 + 1
+    for name, rays in (("coherent", _coherent(side, dev)), ("incoherent", _incoherent(n_rays, dev))):
+        n = rays.shape[0]
+        assert n == n_rays
+        hits = torch.empty((n, 4), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        gpu.trace_closest_device(rays.data_ptr(), n, hits.data_ptr())
+        prim = hits[:, 0].view(torch.int32)
+        checksum = int((prim.long() * weights).sum().item())
+        stride = n // n_check
+        sub = rays[::stride].cpu().numpy()
+        got = hits[::stride].cpu().numpy()
+        pieces = np.array_split(np.arange(len(sub)), 16)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(16) as pool:
+            want = list(pool.map(lambda ix: checker.trace_closest(sub[ix]), pieces))
+        idx = np.concatenate([x[0] for x in want])
+        assert np.array_equal(got[:, 0].view(np.int32), idx), f"{name}: {(got[:, 0].view(np.int32) != idx).sum()} index mismatches"
+        for col, k in ((1, 1), (2, 2), (3, 3)):
+            assert np.array_equal(got[:, col].view(np.uint32), np.concatenate([x[k] for x in want]).view(np.uint32)), name
+        assert 0.9 < (idx >= 0).mean() <= 1.0
+        # again in two halves: same hits, so the same checksum
+        hits2 = torch.empty_like(hits)
+        half = n // 2
+        gpu.trace_closest_device(rays.data_ptr(), half, hits2.data_ptr())
+        gpu.trace_closest_device(rays[half:].data_ptr(), n - half, hits2[half:].data_ptr())
+        assert int((hits2[:, 0].view(torch.int32).long() * weights).sum().item()) == checksum, name
+        assert torch.equal(hits2.view(torch.int32), hits.view(torch.int32)), name
+        del hits, hits2, rays
+
+
+@pytest.mark.parametrize("name", ["dragon.txt", "cornell_box.txt"])
+def test_bulk_rays_bit_exact(gpu, name):
+    """8 Mi rays per scene (random, starting on the geometry, axis-parallel on a
+    grid) through both ray-batch entry points against the checker: this is where
+    rare events (box decisions that need the exact quotients, ties) show."""
+    from concurrent.futures import ThreadPoolExecutor
+    path = f"{orc.SCENES}/{name}"
+    osc = orc.Scene.load(path).build_bvh()
+    psc = rta.Scene.load(path).build_bvh()
+    gpu.upload(psc)
+    nodes = osc.nodes()
+    lo, hi = nodes["lo"][0], nodes["hi"][0]
+    pad = (hi - lo) * 0.25
+    chunk = 1 << 20
+    with ThreadPoolExecutor(16) as pool:
+        for part in range(8):
+            rng = np.random.default_rng(7000 + part)
+            rr = raygen.random_rays(chunk, lo - pad, hi + pad, seed=9000 + part).astype(np.float32)
+            if part % 4 == 1:
+                got0 = gpu.trace_closest(rr)
+                hit = got0["prim"] >= 0
+                rr[hit, 0:3] = rr[hit, 0:3] + rr[hit, 3:6] * got0["t"][hit, None]
+                d = rng.standard_normal((chunk, 3)).astype(np.float32)
+                rr[:, 3:6] = d / np.linalg.norm(d, axis=1, keepdims=True)
+            if part % 4 == 2:
+                rr[:, 3:6] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, chunk)] * rng.choice([-1, 1], (chunk, 1))
+                rr[:, 0:3] = np.round(rr[:, 0:3] * 8) / 8
+            dist = (rng.random(chunk, dtype=np.float32) * np.float32(np.linalg.norm(hi - lo))).astype(np.float32)
+            got = gpu.trace_closest(rr)
+            occ = gpu.trace_occluded(rr, dist)
+            pieces = np.array_split(np.arange(chunk), 16)
+            want = list(pool.map(lambda ix: osc.trace_closest(rr[ix]), pieces))
+            wocc = np.concatenate(list(pool.map(lambda ix: osc.trace_occluded(rr[ix], dist[ix]), pieces)))
+            idx = np.concatenate([x[0] for x in want])
+            same = got["prim"] == idx
+            for key, k in (("t", 1), ("u", 2), ("v", 3)):
+                ref = np.concatenate([x[k] for x in want])
+                same &= (got[key].view(np.uint32) == ref.view(np.uint32)) | ((idx < 0) & (key != "t"))
+            same &= occ.astype(bool) == wocc.astype(bool)
+            assert same.all(), f"{name} part {part}: {(~same).sum()} mismatches, first ray {rr[np.nonzero(~same)[0][0]].tolist()}"
+
+
+@pytest.mark.parametrize("name,floor", [("dragon.txt", 1.13), ("cornell_box.txt", 3.31)])
+def test_image_within_tolerance_of_the_reference_render(gpu, name, floor):
+    """Against an image rendered by the REFERENCE BINARY (200x200, 256 spp,
+    committed under tests/golden): the reference draws one random stream per
+    image row, the GPU path one per (pixel, block), so the two images differ like
+    two renders with different seeds.  Stated tolerance: RMSE over all B,G,R bytes
+    at most 1.5 x the seed-to-seed noise floor of the reference itself at 256 spp
+    (1.13 for dragon.txt, 3.31 for cornell_box.txt, in 8-bit units), and the mean
+    difference per channel - a bias would show here, noise averages out - at most
+    0.3 / 255."""
+    with open(os.path.join(GOLDEN, "golden.json")) as f:
+        meta = json.load(f)["tolerance_renders"]
+    fname = f"ref_{name.split('.')[0]}_200x200x256.bmp"
+    m = meta[fname]
+    want = orc.read_bmp(os.path.join(GOLDEN, fname)).astype(np.float64)
+    psc = rta.Scene.parse(orc.scene_variant(name, m["width"], m["height"], m["samples"])).build_bvh()
+    gpu.upload(psc)
+    bgr = gpu.render_scene(psc, seed=69420, samples_per_stream=16)[0].astype(np.float64)
+    d = bgr - want
+    rmse = float(np.sqrt((d ** 2).mean()))
+    assert rmse <= 1.5 * floor, rmse
+    bias = np.abs(d.reshape(-1, 3).mean(axis=0))
+    assert (bias <= 0.3).all(), bias
+
+
+def test_inverted_boxes_take_the_division_path(gpu):
+    """A caller-made tree may carry a box with min > max.  The reference's slab
+    test picks planes by the direction's sign bit whatever their order; the
+    reciprocal test does not, so such a tree must be traversed with divisions
+    only: compare with the all-division variant of the kernel."""
+    psc = rta.Scene.load(f"{orc.SCENES}/cornell_box.txt").build_bvh()
+    a = psc.arrays()
+    a["node_bounds"] = a["node_bounds"].copy()
+    a["node_bounds"][1, [0, 3]] = a["node_bounds"][1, [3, 0]]        # first leaf: x range inverted
+    desc = rta.desc_from_arrays(a)
+    rta.validate(desc)
+    gpu.upload(desc)
+    nodes = a["node_bounds"]
+    rr = raygen.random_rays(200_000, nodes[0, 0:3] - 0.5, nodes[0, 3:6] + 0.5, seed=4)
+    got = gpu.trace_closest(rr)
+    dev = torch.device("cuda", 0)
+    rt = torch.from_numpy(rr).to(dev)
+    ht = torch.zeros((rr.shape[0], 4), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    gpu.trace_variant_device(2, rt.data_ptr(), rr.shape[0], ht.data_ptr())
+    want = ht.cpu().numpy()
+    assert np.array_equal(want[:, 0].view(np.int32), got["prim"])
+    assert np.array_equal(want[:, 1].view(np.uint32), got["t"].view(np.uint32))
+    # and a render of it goes through (no image-plane shortcuts on such a tree)
+    psc.set_render(32, 32, 2)
+    bgr, acc, st = gpu.render(psc.camera(), 32, 32, 2, sky=(0, 0, 0), samples_per_stream=2)
+    assert st["early_rays"] == 0 and np.isfinite(acc).all()

@@ -213,6 +213,38 @@ def test_deep_chain_is_rejected():
     with pytest.raises(rta.RtaError) as e:
         rta.validate(rta.desc_from_arrays(a))
     assert "depth" in e.value.text
+    assert e.value.code == rta.E_LIMIT        # a size limit of the kernels, not a malformed description
+
+
+def test_degenerate_input_builds_a_tree_the_kernels_cannot_take():
+    """The reference builder bounds the pending second children, not the depth:
+    centroids that halve the remaining range again and again give a chain deeper
+    than 64 levels.  The host builder must reproduce it (as the checker does)
+    and validation must name the limit."""
+    n = 120
+    tri = np.zeros((n, 9), np.float32)
+    for k in range(n):
+        x = -np.float32(2.0) ** np.float32(-k)      # -1, -1/2, -1/4, ...: a midpoint split peels one or two triangles off the
+        #                                              FIRST child's side, so the chain runs down the second children
+        tri[k] = [x, 0, 0, x, 1e-44, 0, x, 0, 1e-44]
+    p = rta.Scene.from_triangles(tri).build_bvh()
+    o = orc.Scene.from_triangles(tri).build_bvh()
+    a = p.arrays()
+    assert np.array_equal(a["node_index"], o.nodes()["index"]) and np.array_equal(a["node_count"], o.nodes()["count"])
+    assert o.depth() > 64
+    with pytest.raises(rta.RtaError) as e:
+        rta.validate(p.desc())
+    assert e.value.code == rta.E_LIMIT and "depth" in e.value.text
+
+
+def test_inverted_boxes_are_accepted():
+    """min > max on an axis is legal in a caller-made tree (the reference's slab
+    test selects planes by the direction's sign bit whatever their order)."""
+    path = os.path.join(orc.SCENES, "cornell_box.txt")
+    a = rta.Scene.load(path).build_bvh().arrays()
+    a["node_bounds"] = a["node_bounds"].copy()
+    a["node_bounds"][1, [0, 3]] = a["node_bounds"][1, [3, 0]]
+    rta.validate(rta.desc_from_arrays(a))
 
 
 def test_synthetic_soup_bvh_equals_checker():

@@ -191,3 +191,22 @@ def test_stream_mode_is_statistically_the_same_image():
     assert noise < 4.0                      # 8-bit units; ~2.3 measured at 64 spp
     assert rmse(other_seed, pm) < noise      # same streams, only last-bit math differences
     assert abs(ref.mean() - pm.mean()) < 0.5
+
+
+@pytest.mark.parametrize("fname,floor", [("ref_dragon_200x200x256.bmp", 1.13), ("ref_cornell_box_200x200x256.bmp", 3.31)])
+def test_stream_mode_within_stated_tolerance_of_reference_bmp(fname, floor):
+    """The image tolerance the GPU tests apply, applied to the checker itself:
+    against the 200x200 x 256 spp image the reference binary rendered, a render
+    from per-(pixel, block) streams with the portable elementary functions has
+    RMSE <= 1.5 x the reference's own seed-to-seed noise floor at 256 spp and a
+    mean difference per channel of at most 0.3 / 255."""
+    meta = G["tolerance_renders"][fname]
+    with open(os.path.join(GOLD, fname), "rb") as f:
+        data = f.read()
+    assert hashlib.md5(data).hexdigest() == meta["md5"]
+    want = orc.read_bmp(data).astype(np.float64)
+    sc = load(meta["scene"]).set_render(meta["width"], meta["height"], meta["samples"])
+    got = sc.render(orc.RNG_STREAM, orc.MATH_PM, seed=69420, samples_per_stream=16)[0].astype(np.float64)
+    d = got - want
+    assert float(np.sqrt((d ** 2).mean())) <= 1.5 * floor
+    assert (np.abs(d.reshape(-1, 3).mean(axis=0)) <= 0.3).all()

@@ -173,6 +173,7 @@ def main():
     width, height = w["width"], w["height"]
 
     scene = rta.Scene.load(os.path.join(ROOT, "scenes", w["scene"])).build_bvh()
+    scene.set_render(width, height, spp_fixed)        # the camera's image plane follows the frame size
     ctx = rta.Context(local)
     ctx.upload(scene)
     cam = scene.camera()

@@ -178,6 +178,20 @@ typedef struct {
  * order; hits[i] always belongs to ray i. */
 int rta_trace_closest(rta_context *ctx, const float *rays, int64_t n, rta_hit *hits, int mem);
 
+/* rta_trace_closest for callers that cannot allocate device memory (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  It
+ * has no counterpart in the reference.  rays and hits are DEVICE pointers on
+ * the context's GPU; results equal rta_trace_closest's bit for bit.  The batch
+ * is traced in the order of its rays' origins, and the workspace for that order
+ * (16 bytes per ray + the sort's temporary storage) is a fixed array in device
+ * memory that the library holds on every GPU it runs on (24 MiB + 256 bytes)
+ * instead of a buffer that grows with n: the call makes no hipMalloc, hipFree
+ * or other allocating call, and rejects n > RTA_STATIC_MAX_RAYS with
+ * RTA_E_LIMIT.  All such calls on one GPU share that array: calls that overlap
+ * in time on one GPU (from several contexts or threads) race. */
+#define RTA_STATIC_MAX_RAYS (1 << 20)
+int rta_trace_closest_static(rta_context *ctx, const float *rays, int64_t n, rta_hit *hits);
+
 /* Any hit closer than tmax[i].  Replaces Occluded (src/main.cpp:424-478). */
 int rta_trace_occluded(rta_context *ctx, const float *rays, const float *tmax, int64_t n, uint8_t *out, int mem);
 

@@ -20,6 +20,7 @@ CLI_PATH = os.path.join(_HERE, "raytracer")
 MEM_HOST, MEM_DEVICE = 0, 1
 PRIM_TRIANGLE, PRIM_SPHERE = 0, 1
 RENDER_TIME_KERNELS, RENDER_COUNT_WORK, RENDER_SMALL_PASSES = 1, 2, 4
+STATIC_MAX_RAYS = 1 << 20
 
 OK = 0
 E_INVALID, E_PARSE, E_IO, E_NO_DEVICE, E_DEVICE, E_NO_SCENE, E_LIMIT = -1, -2, -3, -4, -5, -6, -7
@@ -97,6 +98,7 @@ _SIGNATURES = {
     "rta_last_error": (C.c_char_p, [C.c_void_p]),
     "rta_upload_scene": (C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),
     "rta_trace_closest": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]),
+    "rta_trace_closest_static": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "rta_trace_occluded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]),
     "rta_render": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p, C.c_void_p,
                              C.POINTER(Stats)]),
@@ -351,6 +353,10 @@ class Context:
 
     def trace_closest_device(self, rays_ptr, n, hits_ptr):
         self._check(lib().rta_trace_closest(self._h, rays_ptr, n, hits_ptr, MEM_DEVICE))
+
+    def trace_closest_static_device(self, rays_ptr, n, hits_ptr):
+        """rta_trace_closest_static: device pointers, at most STATIC_MAX_RAYS rays, allocates nothing."""
+        self._check(lib().rta_trace_closest_static(self._h, rays_ptr, n, hits_ptr))
 
     def trace_variant_device(self, variant, rays_ptr, n, hits_ptr):
         self._check(lib().rta_debug_trace_variant(self._h, variant, rays_ptr, n, hits_ptr, MEM_DEVICE))

@@ -64,6 +64,11 @@ int rta_create(int device, rta_context **out)
 		set_global_error(std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only");
 		return RTA_E_NO_DEVICE;
 	}
+	// this GPU's copy of the static workspace of rta_trace_closest_static (the device is current)
+	if ((e = static_scratch_init(device)) != hipSuccess) {
+		set_global_error(std::string("hipGetSymbolAddress(static workspace): ") + hipGetErrorString(e));
+		return RTA_E_DEVICE;
+	}
 	rta_context *ctx = new rta_context();
 	ctx->device = device;
 	e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);

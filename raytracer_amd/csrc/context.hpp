@@ -96,4 +96,8 @@ namespace rta {
 // the uploaded tree as the kernels take it
 TreeRef tree_of(const rta_context *ctx);
 
+// static_trace.hip: looks up the CURRENT device's copy of the library's static
+// workspace array (once per device); the device must be `device`
+hipError_t static_scratch_init(int device);
+
 }  // namespace rta

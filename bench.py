@@ -49,7 +49,7 @@ import raytracer_amd as rta  # noqa: E402
 # triangle test, 16 B per sphere test, 40 B ray in + hit out).
 WORKLOADS = {
     "dragon1080p": dict(scene="dragon.txt", width=1920, height=1080, spp=1024, survey_bytes_per_ray=691.0,
-                        sps=16, cpu_spp=256, label="scenes/dragon.txt 1920x1080 1024spp"),
+                        sps=8, cpu_spp=256, label="scenes/dragon.txt 1920x1080 1024spp"),
     "cornell1080p": dict(scene="cornell_box.txt", width=1920, height=1080, spp=256, survey_bytes_per_ray=764.0,
                          sps=16, cpu_spp=64, label="scenes/cornell_box.txt 1920x1080 256spp"),
     "dragon4k": dict(scene="dragon.txt", width=3840, height=2160, spp=4096, survey_bytes_per_ray=691.0,
@@ -57,7 +57,10 @@ WORKLOADS = {
 }
 # sps: samples per random stream.  A stream's samples are a sequential chain (one wavefront step per
 # path segment), so shorter streams mean more chains in flight and a shorter end of the render, at
-# 16 bytes of block sum per stream.
+# 16 bytes of block sum per stream.  dragon 1080p x 1024 spp on one GPU: 208 / 201 / 197 / 200 ms with
+# 2 / 4 / 8 / 16 samples per stream; one eighth of its tiles (a rank's share of the frame split over
+# 8 GPUs): 32 / 32 / 34 / 42 ms.  The image depends on this number (it defines the streams), so it
+# is one number per workload, not one per GPU count.
 HBM_PEAK_GBS = 8000.0
 L2_PEAK_GBS = 34500.0
 SIMDS, CLOCK_HZ = 1024, 2.4e9
@@ -322,35 +325,42 @@ def roofline(w, excl, count, m):
     queries = count["rays"] - count["early_rays"] + count["shadow_rays"]
     alg_bytes = 64.0 * count["inner_visits"] + 36.0 * count["tri_tests"] + 16.0 * count["sph_tests"] + 40.0 * queries
     closest_share = (count["rays"] - count["early_rays"]) / max(queries, 1)
-    bytes_per_traced = alg_bytes / max(queries, 1)
-    per_launch = bytes_per_traced * traced / launches
-    achieved = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    counted_per_ray = alg_bytes / max(queries, 1)
+    rays_per_launch = traced / launches
+    seconds = avg_ms * 1e-3
+    # The metric's per-query figure x the queries one launch traces / the launch's own duration.  That
+    # figure averages the reference's visits over ALL queries of the workload, the cheap camera rays
+    # that never reach this kernel included, so it under-prices the rays that do (see counted_*).
+    achieved = w["survey_bytes_per_ray"] * rays_per_launch / seconds / 1e9 if seconds > 0 else 0.0
+    counted = counted_per_ray * rays_per_launch / seconds / 1e9 if seconds > 0 else 0.0
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
            "kernel": "k_intersect", "avg_launch_ms": avg_ms, "launches": launches,
-           "rays_per_launch": traced / launches,
-           "bytes_per_ray": bytes_per_traced,
-           "bytes_per_ray_source": "64 B x inner visits + 36 B x triangle tests + 16 B x sphere tests counted on the "
-                                   "device in this run (RTA_RENDER_COUNT_WORK) over the queries that walked the tree, "
-                                   "+ 40 B ray in and hit out",
-           "inner_visits_per_traced_query": count["inner_visits"] / max(queries, 1),
-           "tri_tests_per_traced_query": count["tri_tests"] / max(queries, 1),
-           "closest_hit_share_of_traced_queries": closest_share,
-           # the same with the survey's per-query figure, which averages the reference's visits over ALL queries
-           "frac_at_survey_bytes": w["survey_bytes_per_ray"] * traced / launches / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-           if avg_ms > 0 else 0.0,
-           "survey_bytes_per_ray": w["survey_bytes_per_ray"],
+           "rays_per_launch": rays_per_launch,
+           "bytes_per_ray": w["survey_bytes_per_ray"],
+           "bytes_per_ray_source": "64 B x inner visits + 36 B x triangle tests + 40 B with the reference traversal's "
+                                   "visit counts averaged over every closest-hit query of the workload",
            "timing": "HIP events around every launch of an extra render on ONE stream (nothing overlaps), untimed for "
                      "`value`",
            "exclusive_pass": {"gpu_ms": excl["gpu_ms"], "intersect_ms": excl["intersect_ms"],
                               "advance_ms": excl["advance_ms"], "shadow_ms": excl["shadow_ms"],
                               "advance_launches": excl["advance_launches"],
+                              "traced_mrays_per_s_of_the_kernel_alone": traced / max(excl["intersect_ms"], 1e-9) / 1e3,
                               "kernel_time_over_gpu_time": (excl["intersect_ms"] + excl["advance_ms"] +
                                                             excl["shadow_ms"]) / max(excl["gpu_ms"], 1e-9)},
-           # the tree is L2-resident, so the algorithmic bytes are L2-served: the same figure against the
-           # aggregate L2 bandwidth, for the kernel alone and for the timed region as a whole
-           "l2_frac": achieved / L2_PEAK_GBS, "l2_peak": L2_PEAK_GBS,
-           "pipeline_l2_frac": m["traced_mrays_per_s"] * 1e6 * bytes_per_traced / 1e9 / L2_PEAK_GBS}
+           # What the traced queries really visit, counted on the device in this run (closest-hit and
+           # occlusion traversals share the counters).  The tree is L2-resident, so these bytes are
+           # L2-served: priced against the aggregate L2 bandwidth, for the kernel alone and for the
+           # timed region as a whole.
+           "counted_bytes_per_ray": counted_per_ray,
+           "counted_source": "64 B x inner visits + 36 B x triangle tests + 16 B x sphere tests counted on the device "
+                             "(RTA_RENDER_COUNT_WORK) over the queries that walked the tree, + 40 B ray in and hit out",
+           "inner_visits_per_traced_query": count["inner_visits"] / max(queries, 1),
+           "tri_tests_per_traced_query": count["tri_tests"] / max(queries, 1),
+           "closest_hit_share_of_traced_queries": closest_share,
+           "counted_gbs": counted, "l2_peak": L2_PEAK_GBS, "l2_frac": counted / L2_PEAK_GBS,
+           "pipeline_l2_frac": m["traced_mrays_per_s"] * 1e6 * counted_per_ray / 1e9 / L2_PEAK_GBS}
+    per_launch = w["survey_bytes_per_ray"] * rays_per_launch
     # counter-based figures of this workload from the committed rocprofv3 PMC passes
     ppath = os.path.join(ROOT, "profiles", "pmc_roofline.json")
     if os.path.exists(ppath):

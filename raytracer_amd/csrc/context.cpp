@@ -416,6 +416,7 @@ int rta_upload_scene(rta_context *ctx, const rta_scene_desc *desc)
 		return ctx->fail(f.over_limit ? RTA_E_LIMIT : RTA_E_INVALID, "invalid scene: " + problem);
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	ctx->have_scene = false;
+	ctx->prepared.valid = false;
 	int rc;
 	if ((rc = upload_vec(ctx, ctx->pairs, f.pairs)) || (rc = upload_vec(ctx, ctx->prims, f.prims)) ||
 	    (rc = upload_vec(ctx, ctx->shade_prims, f.shade)) || (rc = upload_vec(ctx, ctx->materials, f.mats)) ||
@@ -829,6 +830,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		a.shadow = ctx->shadow.as<float4>() ? ctx->shadow.as<float4>() + 3 * off : nullptr;
 		a.q_ray = ctx->q_ray.as<uint32_t>() + (size_t)g * group_queue;
 		a.shard_cap = shard_cap;
+		a.grid_cap = shard_cap;
 		a.cnt = ctx->counters.as<Counters>() + g;
 		gs[g] = g == 0 ? ctx->stream : ctx->extra[g - 1];
 	}
@@ -860,10 +862,17 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	HIP_TRY_R(hipEventCreate(&ev_begin));
 	HIP_TRY_R(hipEventCreate(&ev_mid));
 	HIP_TRY_R(hipEventCreate(&ev_end));
-	if (n_pad)
+	// What is prepared here depends only on scene, camera, frame and shard; a render with the
+	// same key as the last one finds it all where that render left it (rta_context::Prepared).
+	rta_context::Prepared &pre = ctx->prepared;
+	const bool reuse = pre.valid && memcmp(&pre.cam, camera, sizeof(rta_camera)) == 0 && pre.width == p->width &&
+	                   pre.height == p->height && pre.shard_index == p->shard_index && pre.shard_count == n_shards &&
+	                   pre.lane_blocks == lane_blocks && pre.with_sky_map == with_sky_map;
+	pre.valid = false;
+	if (n_pad && !reuse)
 		HIP_TRY_R(hipMemcpyAsync(ctx->pixels.ptr, px.data(), (size_t)n_pad * 4, hipMemcpyHostToDevice, s));
 	HIP_TRY_R(hipEventRecord(ev_begin, s));
-	if (with_sky_map)
+	if (with_sky_map && !reuse)
 		launch_sky_map(s, base.tree, ctx->n_pairs, projection, (uint32_t)p->width, (uint32_t)p->height,
 		               ctx->cover.as<uint8_t>(), ctx->sky_map.as<float>());
 	// Heaviest parts of the image first: one ray per pixel tells which parts see
@@ -871,7 +880,11 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	// list the waves draw their items from.
 	uint32_t n_listed = 0, n_far = 0;
 	uint64_t far_pixels = 0;
-	if (n_parts) {
+	if (reuse) {
+		n_listed = pre.n_listed;
+		n_far = pre.n_far;
+		far_pixels = pre.far_pixels;
+	} else if (n_parts) {
 		std::vector<uint32_t> weight(n_parts), order(n_parts);
 		launch_part_weights(s, ga[0], ctx->part_weights.as<uint32_t>(), ctx->stack_depth);
 		HIP_TRY_R(hipMemcpyAsync(weight.data(), ctx->part_weights.ptr, (size_t)n_parts * 4, hipMemcpyDeviceToHost, s));
@@ -901,6 +914,17 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		HIP_TRY_R(hipMemcpyAsync(ctx->part_weights.ptr, far.data(), (size_t)n_far * 4, hipMemcpyHostToDevice, s));
 		HIP_TRY_R(hipStreamSynchronize(s));       // `order` and `far` die here
 	}
+	pre.cam = *camera;
+	pre.width = p->width;
+	pre.height = p->height;
+	pre.shard_index = p->shard_index;
+	pre.shard_count = n_shards;
+	pre.lane_blocks = lane_blocks;
+	pre.with_sky_map = with_sky_map;
+	pre.n_listed = n_listed;
+	pre.n_far = n_far;
+	pre.far_pixels = far_pixels;
+	pre.valid = true;
 	HIP_TRY_R(hipEventRecord(ev_mid, s));
 	for (int g = 1; g < groups; g++)
 		HIP_TRY_R(hipStreamWaitEvent(gs[g], ev_mid, 0));
@@ -908,7 +932,6 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	// every `poll` steps only to notice the end (steps past the end find every
 	// slot retired and do nothing).  The groups' steps are issued round-robin on
 	// their own streams and run concurrently.
-	const int poll = 16;
 	uint64_t steps = 0;
 	auto timed = [&](hipStream_t st_, int kind, auto &&launch) -> hipError_t {
 		if (!time_kernels) {
@@ -967,9 +990,12 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 			}
 			ga[g].n_streams = parts_here * ga[g].streams_per_part;
 			ga[g].grab_at = grab_at;
+			ga[g].grid_cap = shard_cap;
 			launch_init_slots(gs[g], ga[g], group_slots);
 		}
 		bool done = false;
+		int poll = 16;
+		std::vector<uint32_t> live_slots((size_t)groups, group_slots);      // slots of each group that can still hold a path
 		while (!done) {
 			for (int k = 0; k < poll; k++) {
 				for (int g = 0; g < groups; g++) {
@@ -979,7 +1005,9 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 					// first workgroup empties the occlusion queue for the next step
 					HIP_TRY_R(timed(gs[g], 2, [&] { launch_advance(gs[g], a, par); }));
 					if (lights)
-						HIP_TRY_R(timed(gs[g], 1, [&] { launch_shadow(gs[g], a, group_slots, ctx->stack_depth, count_work); }));
+						HIP_TRY_R(timed(gs[g], 1, [&] {
+							launch_shadow(gs[g], a, live_slots[g], ctx->stack_depth, count_work);
+						}));
 					HIP_TRY_R(timed(gs[g], 0, [&] { launch_intersect(gs[g], a, par, ctx->stack_depth, count_work); }));
 				}
 				steps++;
@@ -989,10 +1017,22 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 				HIP_TRY_R(hipMemcpyAsync(&ctx->host_counters[g], ctx->counters.as<Counters>() + g, sizeof(Counters),
 				                         hipMemcpyDeviceToHost, gs[g]));
 			done = true;
+			uint64_t live = 0;
 			for (int g = 0; g < groups; g++) {
 				HIP_TRY_R(hipStreamSynchronize(gs[g]));
-				done = done && ctx->host_counters[g].live == 0;
+				const uint32_t waves = ctx->host_counters[g].live;
+				done = done && waves == 0;
+				live += waves;
+				// A wave that has retired stays retired for the rest of the pass, so the 64 slots of
+				// each wave still live bound what any sub-queue can receive from now on: the
+				// traversal grids shrink with the work instead of covering the queues' capacity.
+				const uint64_t bound = ((uint64_t)waves * 64 + 255) / 256 * 256;
+				ga[g].grid_cap = (uint32_t)std::min<uint64_t>(shard_cap, std::max<uint64_t>(bound, 256));
+				live_slots[g] = (uint32_t)std::min<uint64_t>(group_slots, std::max<uint64_t>(bound, 256));
 			}
+			// near the end the host looks more often: steps past the end are empty launches
+			if (live * 64 * 8 < n_slots)
+				poll = 4;
 		}
 		for (int g = 0; g < groups; g++) {
 			const Counters &c = ctx->host_counters[g];

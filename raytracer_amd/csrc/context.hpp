@@ -72,6 +72,22 @@ struct rta_context {
 	rta::DeviceBuffer io_a, io_b, io_c;       // staging for host-pointer calls
 	rta::Counters *host_counters = nullptr;   // pinned, kMaxGroups entries
 
+	// What a render prepares before its first wavefront step depends only on the
+	// scene, the camera, the frame size and the shard: the owned pixel list, the
+	// map of samples that need no ray, the work list heaviest first and the list of
+	// sky-only parts.  A render with the same key as the one before (the next frame
+	// of a progressive render, the next step of a benchmark) finds them in the
+	// buffers where that render left them.
+	struct Prepared {
+		bool valid = false;
+		rta_camera cam;
+		int32_t width = 0, height = 0, shard_index = 0, shard_count = 0;
+		uint32_t lane_blocks = 0;
+		bool with_sky_map = false;
+		uint32_t n_listed = 0, n_far = 0;
+		uint64_t far_pixels = 0;
+	} prepared;
+
 	int fail(int code, const std::string &text)
 	{
 		error = text;

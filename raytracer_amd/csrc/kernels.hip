@@ -534,7 +534,8 @@ RTA_DEV uint32_t pulling_blocks(uint32_t n_rays, uint32_t rpl) { return (n_rays 
 // (kShards sub-queues x the most a sub-queue can need), then one workgroup per
 // kBlock camera-ray entries (kShards x shard_cap / kBlock); shards innermost so
 // that the first workgroups of all shards start together.  A workgroup with
-// nothing to do leaves at once.
+// nothing to do leaves at once.  The grid is sized by RenderArgs::grid_cap, the
+// host's bound on what a sub-queue can hold this step.
 RTA_DEV uint32_t pulling_grid(uint32_t shard_cap, uint32_t rpl) { return kShards * pulling_blocks(shard_cap, rpl); }
 
 template <bool COUNT>
@@ -544,7 +545,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 	if (blockIdx.x == 0)
 		step_housekeeping(a, par);
 	WorkCount wc = {0, 0, 0};
-	const uint32_t n_pulling = pulling_grid(a.shard_cap, a.rays_per_lane);
+	const uint32_t n_pulling = pulling_grid(a.grid_cap, a.rays_per_lane);
 	if (blockIdx.x < n_pulling) {
 		const uint32_t shard = blockIdx.x % kShards, part = blockIdx.x / kShards;
 		const uint32_t q = ray_queue_index(par, kBounceRays, shard);
@@ -598,7 +599,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 	extern __shared__ uint32_t lds_stack[];
 	if (blockIdx.x == 0)
 		step_housekeeping(a, par);
-	const uint32_t per_kind = kShards * (a.shard_cap / kBlock);
+	const uint32_t per_kind = kShards * (a.grid_cap / kBlock);
 	const int kind = blockIdx.x < per_kind ? kBounceRays : kCameraRays;
 	const uint32_t rem = blockIdx.x < per_kind ? blockIdx.x : blockIdx.x - per_kind;
 	const uint32_t shard = rem % kShards, part = rem / kShards;
@@ -1048,8 +1049,9 @@ void launch_sky_map(hipStream_t s, const TreeRef &tree, uint32_t n_pairs, const 
 
 void launch_intersect(hipStream_t s, const RenderArgs &a, int par, int depth, bool count)
 {
-	const unsigned blocks = kShards * ((a.shard_cap / kBlock + a.rays_per_lane - 1) / a.rays_per_lane) + kShards * (a.shard_cap / kBlock);
-	const unsigned leafwise_blocks = 2 * kShards * (a.shard_cap / kBlock);
+	// (the same arithmetic as pulling_grid / per_kind in the kernels)
+	const unsigned blocks = kShards * ((a.grid_cap + kBlock * a.rays_per_lane - 1) / (kBlock * a.rays_per_lane)) + kShards * (a.grid_cap / kBlock);
+	const unsigned leafwise_blocks = 2 * kShards * (a.grid_cap / kBlock);
 	if (a.leafwise && count)
 		hipLaunchKernelGGL(k_intersect_leafwise<true>, dim3(leafwise_blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);
 	else if (a.leafwise)
@@ -1059,7 +1061,7 @@ void launch_intersect(hipStream_t s, const RenderArgs &a, int par, int depth, bo
 	else
 		hipLaunchKernelGGL(k_intersect<false>, dim3(blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);
 	// on a tame tree odd rays are rare: one workgroup per sub-queue is plenty
-	const unsigned odd_blocks = a.tree.tame ? kShards : kShards * (a.shard_cap / kBlock);
+	const unsigned odd_blocks = a.tree.tame ? kShards : kShards * (a.grid_cap / kBlock);
 	if (count)
 		hipLaunchKernelGGL(k_intersect_odd<true>, dim3(odd_blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);
 	else

@@ -58,6 +58,8 @@ struct RenderArgs {
 	uint32_t n_slots;
 	uint32_t *q_ray;               // closest-hit queues, [step parity][kind][shard][shard_cap] slot numbers
 	uint32_t shard_cap;            // entries per sub-queue, a multiple of the workgroup size
+	uint32_t grid_cap;             // entries per sub-queue that a traversal launch's grid covers: a multiple of the workgroup
+	                               // size, <= shard_cap, and at least the number of slots that can still queue a ray
 	uint32_t rays_per_lane, refill_at;     // bounce-ray traversal: see traverse_pulling
 	uint32_t leafwise;             // the tree has long leaves: traverse_leafwise, one ray per lane (rays_per_lane = 1)
 	// occlusion queue, 3 per entry: (origin, limit) (direction, slot) (radiance, -)
@@ -110,6 +112,7 @@ constexpr int kSkyBorder = 3;     // cells around the frame that the cover map i
 void launch_sky_map(hipStream_t s, const TreeRef &tree, uint32_t n_pairs, const Projection &pr, uint32_t width,
                     uint32_t height, uint8_t *cover, float *sky_map);
 void launch_intersect(hipStream_t s, const RenderArgs &a, int par, int depth, bool count);
+// `bound`: an upper bound on the number of queued occlusion queries
 void launch_shadow(hipStream_t s, const RenderArgs &a, uint32_t bound, int depth, bool count);
 void launch_sum_blocks(hipStream_t s, const float4 *partial, const int32_t *pixels, uint32_t n_pad, uint32_t n_blocks,
                        float *frame, bool resume);

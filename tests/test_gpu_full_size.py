@@ -33,7 +33,7 @@ def load_pair(name, w, h, spp):
     return osc, psc
 
 
-@pytest.mark.parametrize("name,spp,sps", [("dragon.txt", 1024, 16), ("cornell_box.txt", 256, 16)])
+@pytest.mark.parametrize("name,spp,sps", [("dragon.txt", 1024, 8), ("cornell_box.txt", 256, 16)])
 def test_benchmark_frames_bit_exact(gpu, name, spp, sps):
     """dragon.txt 1920x1080 x 1024 spp and cornell_box.txt 1920x1080 x 256 spp,
     the two single-GPU render configurations, at the benchmark's own sample

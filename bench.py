@@ -138,6 +138,9 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
                     help="what `value` measures for N > 1: weak = spp x N (per-GPU work fixed), strong = the fixed "
                          "workload split over the ranks; the other one is reported beside it")
+    ap.add_argument("--sharding", default="tiles", choices=("tiles", "samples"),
+                    help="how N > 1 ranks split a frame: interleaved 8x8 tiles + all-gather (exact, default) or ranges of "
+                         "the sample blocks + all-reduce(sum)")
     ap.add_argument("--samples-per-stream", type=int, default=0, help="0: the workload's own (16 or 32)")
     ap.add_argument("--slots", type=int, default=0)
     ap.add_argument("--run-blocks", type=int, default=0)
@@ -183,18 +186,24 @@ def main():
     s = scene.settings
 
     # outputs live in HBM: the shard's radiance sums land in a frame-sized buffer
-    from raytracer_amd.dist import ShardGather
+    from raytracer_amd.dist import ShardGather, block_ranges, reduce_partial_sums
     frame = torch.zeros((height, width, 3), dtype=torch.float32, device=dev)
     bgr = torch.zeros((height, width, 3), dtype=torch.uint8, device=dev)
     gatherer = ShardGather(width, height, rank, world, dev)
     # the library works on its own streams: everything torch has queued for these buffers must be through
     torch.cuda.synchronize()
 
+    by_samples = args.sharding == "samples" and world > 1
+
     def params(spp, flags=0, streams=None):
         p = rta.RenderParams(width=width, height=height, samples=spp, exposure=s.exposure, seed=69420,
                              samples_per_stream=args.samples_per_stream, shard_index=rank, shard_count=world,
                              slots=args.slots, out_mem=rta.MEM_DEVICE, run_blocks=args.run_blocks,
                              streams=args.streams if streams is None else streams, flags=flags)
+        if by_samples:
+            # every rank renders all pixels for its range of the sample blocks
+            p.shard_index, p.shard_count = 0, 1
+            p.block_begin, p.block_end = block_ranges(spp, args.samples_per_stream, world)[rank]
         p.sky[:] = list(s.sky)
         return p
 
@@ -209,6 +218,17 @@ def main():
         p = params(spp)
 
         def step():
+            if by_samples:
+                if p.block_end > p.block_begin:
+                    st = ctx.render_device(cam, p, frame.data_ptr(), None)
+                else:
+                    frame.zero_()
+                    torch.cuda.synchronize()
+                    st = dict.fromkeys(rta.Stats().as_dict(), 0)
+                reduce_partial_sums(frame, dist)          # radiance reduce over xGMI: one all-reduce(sum) of the frame
+                torch.cuda.current_stream().synchronize()
+                ctx.resolve_device(frame.data_ptr(), width, height, spp, s.exposure, bgr.data_ptr())
+                return st
             st = ctx.render_device(cam, p, frame.data_ptr(), None)
             if world > 1:
                 # radiance gather over xGMI: one all-gather of equal-sized (padded) shards
@@ -250,7 +270,10 @@ def main():
         fence()
         t0 = time.perf_counter()
         for _ in range(5):
-            gatherer.gather(frame, dist)
+            if by_samples:
+                reduce_partial_sums(frame, dist)
+            else:
+                gatherer.gather(frame, dist)
         fence()
         gather_ms = (time.perf_counter() - t0) / 5 * 1e3
 
@@ -290,8 +313,10 @@ def main():
                     "seeded streams" % w["scene"],
             **({"rehearsal": "all ranks on one GPU over gloo: plumbing only"} if rehearsal else {}),
             "config": {"workload": w["label"] if world == 1 else
-                       "%s %dx%d, %d spp in total, 8x8 tiles interleaved over %d GPUs, RCCL all-gather of "
-                       "fp32 radiance" % (w["scene"], width, height, main_run["spp"], world),
+                       "%s %dx%d, %d spp in total, %s" % (
+                           w["scene"], width, height, main_run["spp"],
+                           "sample blocks split over %d GPUs, RCCL all-reduce(sum) of fp32 radiance" % world if by_samples
+                           else "8x8 tiles interleaved over %d GPUs, RCCL all-gather of fp32 radiance" % world),
                        "samples_per_stream": args.samples_per_stream,
                        "rays_per_sample": main_run["queries"] / main_run["samples"]},
         }

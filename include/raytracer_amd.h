@@ -212,6 +212,13 @@ typedef struct {
 	                               * only, results do not depend on it); <= 0: library default */
 	int32_t streams;              /* parts the slot pool is cut into, each stepping on its own HIP stream
 	                               * (scheduling only); <= 0: library default, at most 8 */
+	/* sample-range sharding: render only the sample blocks [block_begin, block_end) of every owned
+	 * pixel (a block = samples_per_stream samples; 0, 0 = all blocks).  accum then receives the sum
+	 * over those blocks only and bgr must be NULL: the caller adds the partial frames of all ranges
+	 * (a sum-reduce over the GPUs) and calls rta_resolve.  The union of the ranges draws exactly the
+	 * samples of an unsplit render; the frame differs from it only by the order of the last fp32
+	 * additions, which is why tile sharding (shard_index / shard_count), exact, is the default. */
+	int32_t block_begin, block_end;
 } rta_render_params;
 
 enum {

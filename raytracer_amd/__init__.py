@@ -60,7 +60,7 @@ class RenderParams(C.Structure):
                 ("sky", C.c_float * 3), ("seed", C.c_uint32), ("samples_per_stream", C.c_int32),
                 ("max_bounces", C.c_int32), ("shard_index", C.c_int32), ("shard_count", C.c_int32),
                 ("slots", C.c_int32), ("out_mem", C.c_int32), ("flags", C.c_int32), ("run_blocks", C.c_int32),
-                ("streams", C.c_int32)]
+                ("streams", C.c_int32), ("block_begin", C.c_int32), ("block_end", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -371,12 +371,12 @@ class Context:
 
     def render(self, camera, width, height, samples, exposure=1.0, sky=(0, 0, 0), seed=69420, samples_per_stream=0,
                max_bounces=0, shard_index=0, shard_count=1, slots=0, flags=0, run_blocks=0, streams=0,
-               want_accum=True, want_bgr=True):
+               block_begin=0, block_end=0, want_accum=True, want_bgr=True):
         """Host-buffer render.  Returns (bgr[h,w,3] uint8, accum[h,w,3] float32, stats dict)."""
         p = RenderParams(width=width, height=height, samples=samples, exposure=exposure, seed=seed,
                          samples_per_stream=samples_per_stream, max_bounces=max_bounces, shard_index=shard_index,
                          shard_count=shard_count, slots=slots, out_mem=MEM_HOST, flags=flags, run_blocks=run_blocks,
-                         streams=streams)
+                         streams=streams, block_begin=block_begin, block_end=block_end)
         p.sky[:] = [float(x) for x in sky]
         bgr = np.zeros((height, width, 3), np.uint8) if want_bgr else None
         acc = np.zeros((height, width, 3), np.float32) if want_accum else None

@@ -690,7 +690,16 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		n_owned += q >= 0;
 	const uint32_t spp = (uint32_t)p->samples;
 	const uint32_t sps = p->samples_per_stream <= 0 ? spp : std::min((uint32_t)p->samples_per_stream, spp);
-	const uint32_t n_blocks = (spp + sps - 1) / sps;
+	// the sample blocks this call renders: all of them, or the caller's range of them (sample-range sharding)
+	const uint32_t all_blocks = (spp + sps - 1) / sps;
+	const bool whole = p->block_begin == 0 && p->block_end == 0;
+	if (!whole && (p->block_begin < 0 || p->block_end <= p->block_begin || (uint32_t)p->block_end > all_blocks))
+		return ctx->fail(RTA_E_INVALID, "block range out of order or beyond the " + std::to_string(all_blocks) + " sample blocks");
+	const uint32_t range_begin = whole ? 0u : (uint32_t)p->block_begin, range_end = whole ? all_blocks : (uint32_t)p->block_end;
+	const bool partial_sum = range_begin != 0 || range_end != all_blocks;
+	if (partial_sum && bgr)
+		return ctx->fail(RTA_E_INVALID, "a render of part of the sample blocks yields partial sums: pass bgr = NULL and resolve the summed frame");
+	const uint32_t n_blocks = range_end - range_begin;
 	const uint32_t run_blocks = p->run_blocks > 0 ? std::min((uint32_t)p->run_blocks, n_blocks) : 1u;
 	const uint32_t n_runs = (n_blocks + run_blocks - 1) / run_blocks;
 	// A wave's 64 lanes work on 64 / lane_blocks pixels of a tile (whole rows of it)
@@ -954,8 +963,8 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	};
 	for (uint32_t g0 = 0; g0 < n_groups && n_parts; g0 += groups_per_pass) {
 		const uint32_t g1 = std::min(n_groups, g0 + groups_per_pass);
-		const uint32_t first_block = g0 * blocks_per_group;
-		const uint32_t end_block = std::min<uint64_t>(n_blocks, (uint64_t)g1 * blocks_per_group);
+		const uint32_t first_block = range_begin + g0 * blocks_per_group;
+		const uint32_t end_block = (uint32_t)std::min<uint64_t>(range_end, (uint64_t)range_begin + (uint64_t)g1 * blocks_per_group);
 		for (int g = 0; g < kMaxGroups; g++) {
 			memset(&ctx->host_counters[g], 0, sizeof(Counters));
 			ctx->host_counters[g].live = g < groups ? group_slots / 64 : 0;
@@ -1090,7 +1099,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 			st.shadow_launches++;
 		}
 	}
-	st.samples = (uint64_t)n_owned * spp;
+	st.samples = (uint64_t)n_owned * (std::min<uint64_t>(spp, (uint64_t)range_end * sps) - (uint64_t)range_begin * sps);
 	st.steps = steps;
 	if (stats)
 		*stats = st;

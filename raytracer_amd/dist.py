@@ -1,5 +1,12 @@
 """Assembling one frame from per-GPU shards with torch.distributed.
 
+Two ways to split a frame (raytracer_amd.h, rta_render_params):
+
+* tiles (ShardGather, the default): exact, one all-gather;
+* sample ranges (block_ranges + reduce_partial_sums): every rank renders all
+  pixels for its share of the sample blocks, one all-reduce(sum) of the frame;
+  equal to the unsplit frame up to the order of the last fp32 additions.
+
 Each rank renders the 8x8 tiles with tile_id % world == rank
 (rta_shard_pixels); the radiance sums of all ranks are brought together with
 ONE all-gather of equally sized (padded) shard buffers - over RCCL/xGMI when
@@ -44,3 +51,25 @@ class ShardGather:
     @property
     def bytes_per_rank(self):
         return self.pad * 12
+
+
+def block_ranges(samples, samples_per_stream, world):
+    """[begin, end) sample-block range of every rank: the blocks cut into `world` near-equal runs
+    (empty, begin == end, for ranks beyond the number of blocks: such a rank renders nothing)."""
+    # (samples_per_stream <= 0 means one stream, hence one block, per pixel: rta_render_params)
+    n_blocks = 1 if samples_per_stream <= 0 else -(-samples // min(samples_per_stream, samples))
+    cuts = [n_blocks * r // world for r in range(world + 1)]
+    return list(zip(cuts[:-1], cuts[1:]))
+
+
+def reduce_partial_sums(frame, dist):
+    """frame: [height, width, 3] float32 holding this rank's partial radiance sums over its block
+    range; on return every rank holds the sums over all samples."""
+    if dist is not None and dist.get_world_size() > 1:
+        if frame.is_cuda and dist.get_backend() == "gloo":
+            host = frame.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            frame.copy_(host)
+        else:
+            dist.all_reduce(frame, op=dist.ReduceOp.SUM)
+    return frame

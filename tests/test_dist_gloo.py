@@ -13,7 +13,7 @@ import torch.multiprocessing as mp
 
 import orc
 import raytracer_amd as rta
-from raytracer_amd.dist import ShardGather
+from raytracer_amd.dist import ShardGather, block_ranges, reduce_partial_sums
 
 W, H, SPP = 52, 37, 3          # ragged: neither dimension is a multiple of the tile
 
@@ -54,3 +54,28 @@ def test_gather_is_identity_for_one_rank():
     g = ShardGather(W, H, 0, 1, torch.device("cpu"))
     assert g.gather(frame.clone(), None).equal(frame)
     assert g.counts == [W * H]
+
+
+def _reduce_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # every rank contributes a frame that depends on its block range; the sum must be the same everywhere
+        b0, b1 = block_ranges(37, 4, world)[rank]
+        frame = torch.full((H, W, 3), float(b1 - b0), dtype=torch.float32) + torch.arange(H * W * 3).reshape(H, W, 3) * (rank + 1)
+        reduce_partial_sums(frame, dist)
+        np.save(os.path.join(out_dir, f"sum{rank}.npy"), frame.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sample_range_reduce(tmp_path):
+    world = 3
+    ranges = block_ranges(37, 4, world)
+    assert ranges[0][0] == 0 and ranges[-1][1] == 10 and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    assert block_ranges(8, 0, 2) == [(0, 0), (0, 1)] and block_ranges(8, 2, 2) == [(0, 2), (2, 4)]
+    mp.spawn(_reduce_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    frames = [np.load(tmp_path / f"sum{r}.npy") for r in range(world)]
+    want = 10.0 + np.arange(H * W * 3, dtype=np.float32).reshape(H, W, 3) * 6
+    for f in frames:
+        assert np.array_equal(f, want)

@@ -196,6 +196,43 @@ def test_shards_assemble_to_the_single_gpu_frame(gpu, name, w, h, spp, sps):
     assert np.array_equal(gpu.resolve(whole_acc, spp, psc.settings.exposure), whole_bgr)
 
 
+@pytest.mark.parametrize("name,w,h,spp,sps", [("cornell_box.txt", 61, 35, 24, 2), ("dragon.txt", 64, 48, 20, 3)])
+def test_sample_ranges_sum_to_the_whole_render(gpu, name, w, h, spp, sps):
+    """Sample-range sharding: every rank renders all pixels for a range of the
+    sample blocks and the partial sums are added (a sum-reduce).  The ranges
+    together draw exactly the samples of the unsplit render, so ray counts add
+    up exactly and the summed frame equals the unsplit one up to the order of
+    the last fp32 additions: stated tolerance 4 ulp of the pixel sum per
+    channel, and the resolved bytes may differ by one step in a few pixels."""
+    osc, psc = load_pair(name)
+    psc.set_render(w, h, spp)
+    gpu.upload(psc)
+    s = psc.settings
+    whole_bgr, whole, whole_st = gpu.render_scene(psc, seed=31, samples_per_stream=sps)
+    n_blocks = -(-spp // sps)
+    for cuts in ([0, n_blocks // 2, n_blocks], [0, 1, 2, n_blocks - 1, n_blocks], [0, n_blocks]):
+        total = np.zeros_like(whole, dtype=np.float32)
+        rays = samples = 0
+        for b0, b1 in zip(cuts[:-1], cuts[1:]):
+            _, part, st = gpu.render(psc.camera(), w, h, spp, exposure=s.exposure, sky=tuple(s.sky), seed=31,
+                                     samples_per_stream=sps, block_begin=b0, block_end=b1, want_bgr=False)
+            total = (total + part).astype(np.float32)
+            rays += st["rays"] + st["shadow_rays"]
+            samples += st["samples"]
+        assert samples == w * h * spp and rays == whole_st["rays"] + whole_st["shadow_rays"], cuts
+        if len(cuts) == 2:
+            assert np.array_equal(bits(total), bits(whole))            # one range holding every block is the whole render
+        tol = 4 * np.spacing(np.maximum(np.abs(whole), np.float32(1e-6)).astype(np.float32))
+        assert (np.abs(total - whole) <= tol).all(), cuts
+        got = gpu.resolve(total, spp, s.exposure)
+        assert (np.abs(got.astype(np.int32) - whole_bgr.astype(np.int32)) <= 1).all()
+        assert (got != whole_bgr).mean() < 0.01
+    with pytest.raises(rta.RtaError):
+        gpu.render(psc.camera(), w, h, spp, samples_per_stream=sps, block_begin=0, block_end=n_blocks + 1, want_bgr=False)
+    with pytest.raises(rta.RtaError):       # a partial sum cannot be tone-mapped
+        gpu.render(psc.camera(), w, h, spp, samples_per_stream=sps, block_begin=0, block_end=1)
+
+
 def test_scheduling_knobs_do_not_change_the_image(gpu):
     osc, psc = load_pair("cornell_box.txt")
     psc.set_render(40, 24, 6)

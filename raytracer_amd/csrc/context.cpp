@@ -618,15 +618,15 @@ int rta_resolve(rta_context *ctx, const float *accum, int32_t width, int32_t hei
 	return RTA_OK;
 }
 
-// Can samples be decided on the image plane (see k_sky_map)?  Only for a pinhole
-// camera (every ray starts at the camera's origin) that sees all of the scene's
+// Can samples be decided on the image plane (see k_sky_map)?  Only for a camera
+// (pinhole, or a lens parallel to the image plane) that sees all of the scene's
 // box well in front of it, with perpendicular image axes.  The margin by which
 // the projected boxes are widened is 0.05 pixels + 1e-5 radians: orders of
 // magnitude more than the binary32 roundings of a sample's point on the image
 // plane, of its ray and of the reference's slab test can move either.
 static bool projection_of(const rta_camera &cam, const TreeRef &tree, Projection &pr)
 {
-	if (!tree.box_known || cam.defocus_angle > 0)
+	if (!tree.box_known)
 		return false;
 	for (int k = 0; k < 3; k++) {
 		pr.o[k] = cam.origin[k];
@@ -654,6 +654,24 @@ static bool projection_of(const rta_camera &cam, const TreeRef &tree, Projection
 			depth += ((double)((c >> k) & 1 ? tree.box_hi[k] : tree.box_lo[k]) - pr.o[k]) * pr.n[k];
 		const double scale = pr.h / depth;
 		if (!(scale > 0) || !(scale < 1e6))
+			return false;
+	}
+	// Lens cameras (src/main.cpp:665-669): origins o + a lens_u + b lens_v, a and b in [-1, 1).  The
+	// lens must lie in a plane parallel to the image plane (it does for rta_camera_from_settings).
+	pr.lens_x = pr.lens_y = 0;
+	if (cam.defocus_angle > 0) {
+		double lu_n = 0, lv_n = 0, lu_du = 0, lv_du = 0, lu_dv = 0, lv_dv = 0, lu2 = 0, lv2 = 0;
+		for (int k = 0; k < 3; k++) {
+			lu_n += cam.lens_u[k] * pr.n[k], lv_n += cam.lens_v[k] * pr.n[k];
+			lu_du += cam.lens_u[k] * pr.du[k], lv_du += cam.lens_v[k] * pr.du[k];
+			lu_dv += cam.lens_u[k] * pr.dv[k], lv_dv += cam.lens_v[k] * pr.dv[k];
+			lu2 += (double)cam.lens_u[k] * cam.lens_u[k], lv2 += (double)cam.lens_v[k] * cam.lens_v[k];
+		}
+		if (!(fabs(lu_n) <= 1e-6 * sqrt(lu2 * n2)) || !(fabs(lv_n) <= 1e-6 * sqrt(lv2 * n2)))
+			return false;
+		pr.lens_x = (fabs(lu_du) + fabs(lv_du)) / pr.du2;
+		pr.lens_y = (fabs(lu_dv) + fabs(lv_dv)) / pr.dv2;
+		if (!std::isfinite(pr.lens_x) || !std::isfinite(pr.lens_y))
 			return false;
 	}
 	// one pixel is sqrt(min(du2, dv2)) wide on a plane |h| / |n| away

@@ -755,6 +755,9 @@ __global__ __launch_bounds__(kBlock) void k_fill_far(const RenderArgs a, const u
 // quotients - ends in the sky.  For a pinhole camera all rays of the image start
 // at one point, and a box is then missed by every ray whose point on the image
 // plane lies outside the rectangle around the box's eight projected corners.
+// A lens camera's rays start anywhere on the lens; seen from all of its points a
+// corner covers a small parallelogram on the image plane (Projection::lens_x),
+// and the rectangle is taken around those.
 //
 // k_cover_leaves marks the pixel-sized cells of the image plane (the frame and
 // kSkyBorder cells around it) that some leaf's rectangle, widened by the margin,
@@ -794,8 +797,11 @@ __global__ __launch_bounds__(kBlock) void k_cover_leaves(const TreeRef tree, con
 		y /= pr.dv2;
 		if (!(x > -1e9 && x < 1e9 && y > -1e9 && y < 1e9))
 			everywhere = true;
-		x0 = x < x0 ? x : x0, x1 = x > x1 ? x : x1;
-		y0 = y < y0 ? y : y0, y1 = y > y1 ? y : y1;
+		// where the lens's other points see this corner (nothing for a pinhole)
+		const double off = scale > 1 ? scale - 1 : 1 - scale;
+		const double sx = off * pr.lens_x * (1 + 1e-9), sy = off * pr.lens_y * (1 + 1e-9);
+		x0 = x - sx < x0 ? x - sx : x0, x1 = x + sx > x1 ? x + sx : x1;
+		y0 = y - sy < y0 ? y - sy : y0, y1 = y + sy > y1 ? y + sy : y1;
 	}
 	if (everywhere) {
 		x0 = y0 = -1e9;

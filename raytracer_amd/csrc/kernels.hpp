@@ -105,6 +105,11 @@ struct Projection {
 	double o[3], ul[3], du[3], dv[3], n[3];
 	double h, du2, dv2;
 	double margin;       // pixels by which every projected box is widened
+	// Lens cameras: a ray starts at o + a lens_u + b lens_v with a, b in [-1, 1).  The lens lies in a
+	// plane parallel to the image plane, so a point at depth h / s is seen at its pinhole position
+	// shifted by (1 - s)(a lens_u + b lens_v): at most |1 - s| lens_x pixels across and |1 - s| lens_y
+	// pixels down.  Both are 0 for a pinhole.
+	double lens_x, lens_y;
 };
 constexpr int kSkyBorder = 3;     // cells around the frame that the cover map includes, and the search radius
 

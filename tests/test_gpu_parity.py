@@ -288,6 +288,26 @@ def test_features_unused_by_the_shipped_scenes(gpu):
     assert np.array_equal(bgr, want_bgr)
 
 
+@pytest.mark.parametrize("angle,look_at", [(2.0, "[0 0 1]"), (0.7, "[2 0.2 1.1]")])
+def test_lens_camera_on_the_dragon_bit_exact(gpu, angle, look_at):
+    """dragon.txt through a lens (focus on the mesh, and far behind it): most
+    samples around the blurred silhouette are decided on the image plane, where
+    a lens point sees a box shifted by (1 - h / depth) times its offset; all
+    480 x 270 x 64 samples must agree with the checker's full computation."""
+    text = orc.scene_variant("dragon.txt", 480, 270, 64).replace("look_at [0 0 1]", f"look_at {look_at}\n\tdefocus_angle {angle}")
+    assert "defocus_angle" in text
+    osc = orc.Scene.parse(text).build_bvh()
+    psc = rta.Scene.parse(text).build_bvh()
+    gpu.upload(psc)
+    want_bgr, want_acc, cn = osc.render(orc.RNG_STREAM, orc.MATH_PM, seed=5, samples_per_stream=8)
+    bgr, acc, st = gpu.render_scene(psc, seed=5, samples_per_stream=8)
+    assert st["rays"] == cn["rays"]
+    assert st["early_rays"] > 0.5 * st["rays"]
+    same = bits(acc) == bits(want_acc)
+    assert same.all(), f"{(~same).any(axis=2).sum()} pixels differ in radiance bits"
+    assert np.array_equal(bgr, want_bgr)
+
+
 def _box_mesh(lo, hi):
     """12 triangles of the axis-parallel box lo..hi as a triangle_mesh block."""
     (x0, y0, z0), (x1, y1, z1) = lo, hi
@@ -304,21 +324,25 @@ _SPHERES = ("sphere {\n\tcenter [0 -0.3 0.1]\n\tradius 0.45\n}\n\nsphere {\n\tce
             "sphere {\n\tcenter [-0.4 0.1 0.6]\n\tradius 0.2\n}\n")
 
 
-@pytest.mark.parametrize("camera,look_at,geometry", [
-    ("[-3 0 0.1]", "[0 0 0.1]", "box"),          # seen along an axis: the outline is the projected box on all four sides
-    ("[-2.5 1.3 0.9]", "[0 0.1 0]", "box"),
-    ("[-2.2 0.4 0.3]", "[0 0 0.1]", "spheres"),
-    ("[-2.5 1.3 0.9]", "[0 1.1 0.9]", "box"),    # the mesh is cut by the edge of the frame
+@pytest.mark.parametrize("camera,look_at,geometry,lens", [
+    ("[-3 0 0.1]", "[0 0 0.1]", "box", ""),          # seen along an axis: the outline is the projected box on all four sides
+    ("[-2.5 1.3 0.9]", "[0 0.1 0]", "box", ""),
+    ("[-2.2 0.4 0.3]", "[0 0 0.1]", "spheres", ""),
+    ("[-2.5 1.3 0.9]", "[0 1.1 0.9]", "box", ""),    # the mesh is cut by the edge of the frame
+    # lens cameras: the outline is blurred by the lens; focus in front of, inside and behind the mesh
+    ("[-3 0 0.1]", "[0 0 0.1]", "box", "defocus_angle 3"),
+    ("[-2.5 1.3 0.9]", "[-1.5 0.8 0.55]", "box", "defocus_angle 1.5"),
+    ("[-2.2 0.4 0.3]", "[3 -0.5 0]", "spheres", "defocus_angle 0.8"),
 ])
-def test_samples_answered_on_the_image_plane(gpu, camera, look_at, geometry):
+def test_samples_answered_on_the_image_plane(gpu, camera, look_at, geometry, lens):
     """Camera samples whose pixel-filter radius cannot reach the projection of
     any leaf's box are given the sky without a ray.  A box-shaped mesh fills
     its own bounding box and a sphere touches all six faces of its own, so the
     pixels around their outlines mix samples decided either way, and all must
     agree with the checker's full computation."""
-    text = ("render {\n\tcamera %s\n\tlook_at %s\n\tsamples 96\n\twidth 44\n\theight 40\n"
+    text = ("render {\n\tcamera %s\n\tlook_at %s\n\t%s\n\tsamples 96\n\twidth 44\n\theight 40\n"
             "\tsky_box_color [.5 .6 1]\n}\n\nmaterial {\n\tcolor [0.8 0.3 0.2]\n\tior 1.5\n\troughness 1\n\tmetallic 0\n}\n\n"
-            % (camera, look_at)) + (_box_mesh((-0.5, -0.62, -0.41), (0.5, 0.57, 0.63)) if geometry == "box" else _SPHERES)
+            % (camera, look_at, lens)) + (_box_mesh((-0.5, -0.62, -0.41), (0.5, 0.57, 0.63)) if geometry == "box" else _SPHERES)
     osc = orc.Scene.parse(text).build_bvh()
     psc = rta.Scene.parse(text).build_bvh()
     gpu.upload(psc)

@@ -11,7 +11,7 @@ OUT := raytracer_amd
 CXXFLAGS := -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Iinclude -I$(SRC) -Wall -Wno-unused-result
 HIPFLAGS := --offload-arch=$(ARCH) $(CXXFLAGS)
 
-OBJS := build/kernels.o build/variants.o build/bvh_build.o build/sort_rays.o build/static_trace.o build/context.o build/api.o build/host_scene.o
+OBJS := build/kernels.o build/variants.o build/bvh_build.o build/sort_rays.o build/static_trace.o build/context.o build/api.o build/host_scene.o build/wide_tree.o
 HDRS := $(wildcard $(SRC)/*.hpp) include/raytracer_amd.h include/rt_pmath.h
 
 all: $(OUT)/libraytracer_amd.so $(OUT)/raytracer

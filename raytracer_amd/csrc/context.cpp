@@ -8,6 +8,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -16,6 +17,7 @@
 #include "context.hpp"
 #include "host_scene.hpp"
 #include "kernels.hpp"
+#include "wide_tree.hpp"
 
 namespace rta {
 
@@ -124,6 +126,10 @@ TreeRef tree_of(const rta_context *ctx)
 	t.box_known = ctx->box_known ? 1u : 0u;
 	memcpy(t.box_lo, ctx->box, 12);
 	memcpy(t.box_hi, ctx->box + 3, 12);
+	t.wide = ctx->have_wide ? ctx->wide_nodes.as<const float4>() : nullptr;
+	t.leaf_boxes = ctx->leaf_boxes.as<const float4>();
+	memcpy(t.wide_center, ctx->wide_center, 12);
+	t.wide_reach2 = ctx->wide_reach2;
 	return t;
 }
 
@@ -277,7 +283,7 @@ std::string flatten(const rta_scene_desc &d, Flattened &out)
 		out.ref_nodes[(size_t)k * 2 + 1] =
 		    make_float4(b[4], b[5], as_float((uint32_t)d.node_index[k]), as_float((uint32_t)d.node_count[k]));
 	}
-	out.prims.resize((size_t)d.n_prims * 3);
+	out.prims.assign((size_t)d.n_prims * kPrimQuads, make_float4(0, 0, 0, 0));
 	out.shade.resize((size_t)d.n_prims * 3);
 	for (int32_t k = 0; k < d.n_prims; k++) {
 		const float *g = d.prim_geom + (size_t)k * 9, *nn = d.prim_normals + (size_t)k * 9;
@@ -285,14 +291,14 @@ std::string flatten(const rta_scene_desc &d, Flattened &out)
 		uint32_t flags = (last_flag[k] || !covered[k]) ? kLastFlag : 0;
 		if (d.prim_type[k] == RTA_PRIM_SPHERE) {
 			flags |= kSphereFlag;
-			out.prims[(size_t)k * 3 + 0] = make_float4(g[0], g[1], g[2], as_float(flags));
-			out.prims[(size_t)k * 3 + 1] = make_float4(g[3], 0, 0, 0);
-			out.prims[(size_t)k * 3 + 2] = make_float4(0, 0, 0, 0);
+			out.prims[(size_t)k * kPrimQuads + 0] = make_float4(g[0], g[1], g[2], as_float(flags));
+			out.prims[(size_t)k * kPrimQuads + 1] = make_float4(g[3], 0, 0, 0);
+			out.prims[(size_t)k * kPrimQuads + 2] = make_float4(0, 0, 0, 0);
 		} else {
 			// e0 = v0 - v2, e1 = v1 - v2 (src/main.cpp:252-253), rounded once in fp32
-			out.prims[(size_t)k * 3 + 0] = make_float4(g[6], g[7], g[8], as_float(flags));
-			out.prims[(size_t)k * 3 + 1] = make_float4(g[0] - g[6], g[1] - g[7], g[2] - g[8], 0);
-			out.prims[(size_t)k * 3 + 2] = make_float4(g[3] - g[6], g[4] - g[7], g[5] - g[8], 0);
+			out.prims[(size_t)k * kPrimQuads + 0] = make_float4(g[6], g[7], g[8], as_float(flags));
+			out.prims[(size_t)k * kPrimQuads + 1] = make_float4(g[0] - g[6], g[1] - g[7], g[2] - g[8], 0);
+			out.prims[(size_t)k * kPrimQuads + 2] = make_float4(g[3] - g[6], g[4] - g[7], g[5] - g[8], 0);
 		}
 		out.shade[(size_t)k * 3 + 0] = make_float4(nn[0], nn[1], nn[2], as_float((uint32_t)d.prim_material[k]));
 		out.shade[(size_t)k * 3 + 1] = make_float4(nn[3], nn[4], nn[5], as_float((uint32_t)d.prim_light[k]));
@@ -422,7 +428,21 @@ int rta_upload_scene(rta_context *ctx, const rta_scene_desc *desc)
 	    (rc = upload_vec(ctx, ctx->shade_prims, f.shade)) || (rc = upload_vec(ctx, ctx->materials, f.mats)) ||
 	    (rc = upload_vec(ctx, ctx->lights, f.lights)) || (rc = upload_vec(ctx, ctx->ref_nodes, f.ref_nodes)))
 		return rc;
+	// the second tree, for the certified traversal
+	ctx->have_wide = false;
+	WideTree wide = build_wide_tree(*desc, f.tame);
+	if (wide.enabled) {
+		if ((rc = upload_vec(ctx, ctx->wide_nodes, wide.nodes)) || (rc = upload_vec(ctx, ctx->leaf_boxes, wide.leaf_boxes)))
+			return rc;
+		memcpy(ctx->wide_center, wide.center, 12);
+		ctx->wide_reach2 = wide.reach * wide.reach * (1.f - 0x1p-20f);
+		ctx->wide_depth = wide.depth;
+	}
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // the staging vectors die with this call
+	ctx->have_wide = wide.enabled;
+	if (getenv("RTA_WIDE_VERBOSE"))
+		fprintf(stderr, "wide tree: %s%s, %u nodes, depth %d, padding/extent %.4f, reach %g\n", wide.enabled ? "built" : "none: ",
+		        wide.why_not.c_str(), wide.n_nodes, wide.depth, wide.mean_pad_over_extent, wide.reach);
 	ctx->root_ref = f.root;
 	ctx->n_pairs = (uint32_t)(f.pairs.size() / 4);
 	ctx->box_known = f.box_known;
@@ -457,7 +477,7 @@ int64_t rta_shard_pixels(int32_t width, int32_t height, int32_t shard_index, int
 static int tracing_order(rta_context *ctx, const float *d_rays, int64_t n, const uint32_t *&order)
 {
 	order = nullptr;
-	const size_t tree_bytes = (size_t)ctx->n_pairs * 64 + (size_t)ctx->n_prims * 48;
+	const size_t tree_bytes = (size_t)ctx->n_pairs * 64 + (size_t)ctx->n_prims * 16 * kPrimQuads;
 	if (!ctx->box_known || n < (1 << 16) || n >= ((int64_t)1 << 32) || tree_bytes < ((size_t)8 << 20))
 		return RTA_OK;
 	const uint32_t count = (uint32_t)n;
@@ -519,6 +539,17 @@ int rta_debug_trace_variant(rta_context *ctx, int variant, const float *rays, in
 		return rta_trace_closest(ctx, rays, n, hits, mem);
 	if (!ctx->have_scene)
 		return ctx->fail(RTA_E_NO_SCENE, "no scene uploaded");
+	if (variant == 20) {
+		if (!ctx->have_wide)
+			return ctx->fail(RTA_E_INVALID, "the scene has no wide tree");
+		if (n <= 0 || !rays || !hits || mem != RTA_MEM_DEVICE)
+			return ctx->fail(RTA_E_INVALID, "variant 20 takes device-resident ray batches");
+		HIP_TRY(ctx, hipSetDevice(ctx->device));
+		launch_wide_batch(ctx->stream, tree_of(ctx), rays, (uint64_t)n, hits, ctx->stack_depth);
+		HIP_TRY(ctx, hipGetLastError());
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		return RTA_OK;
+	}
 	if (variant < 1 || (variant > 5 && variant < 100) || variant > 360 || (variant >= 200 && variant - 200 < ctx->stack_depth) || n <= 0 || !rays || !hits || mem != RTA_MEM_DEVICE)
 		return ctx->fail(RTA_E_INVALID, "variants 1..4 take device-resident ray batches");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));

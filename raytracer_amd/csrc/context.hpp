@@ -54,6 +54,10 @@ struct rta_context {
 	// scene
 	bool have_scene = false;
 	rta::DeviceBuffer pairs, prims, shade_prims, materials, lights, ref_nodes;
+	rta::DeviceBuffer wide_nodes, leaf_boxes;     // the 4-wide tree of the certified traversal (wide_tree.hpp)
+	bool have_wide = false;
+	float wide_center[3] = {0, 0, 0}, wide_reach2 = 0;
+	int wide_depth = 0;
 	rta::DeviceBuffer soa_nodes;      // variant 5 only, made from `pairs` on first use
 	uint32_t n_pairs = 0;
 	bool have_soa = false;

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 			const V3 point = ray.o + ray.d * t;
 			V3 normal;
 			if (is_sphere) {
-				const float4 g0 = a.tree.prims[3 * (size_t)prim], g1 = a.tree.prims[3 * (size_t)prim + 1];
+				const float4 g0 = a.tree.prims[kPrimQuads * (size_t)prim], g1 = a.tree.prims[kPrimQuads * (size_t)prim + 1];
 				normal = (point - xyz(g0)) / g1.x;
 			} else {
 				const float bw = 1 - bu - bv;

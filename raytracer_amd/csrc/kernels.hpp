@@ -10,6 +10,8 @@
 
 namespace rta {
 
+// 16-byte quads per primitive record: three hold it, the fourth keeps a record inside one 64-byte line
+constexpr int kPrimQuads = 4;
 constexpr uint32_t kShards = 64;      // sub-queues per ray queue
 constexpr uint32_t kRayKinds = 3;     // camera rays, bounce rays, rays needing the division-based box test
 
@@ -33,7 +35,16 @@ struct TreeRef {
 	uint32_t tame;           // every box coordinate is 0 or within [2^-78, 2^40] in magnitude
 	uint32_t box_known;      // box_lo/box_hi hold the box around the root's two children (tame trees with an inner root)
 	float box_lo[3], box_hi[3];
+	// The 4-wide tree of the certified traversal (traverse_wide.hpp, wide_tree.hpp); null when the scene has none.
+	const float4 *wide;          // 4 quads per node
+	const float4 *leaf_boxes;    // 2 quads per primitive: the box of its leaf in the reference's tree
+	float wide_center[3];        // a ray may take the wide tree when |origin - wide_center|^2 <= wide_reach2
+	float wide_reach2;           //   and |direction|^2 <= kWideMaxDir^2
 };
+
+constexpr uint32_t kWideLeaf = 0x80000000u;     // child reference of a wide node: kWideLeaf | primitive,
+constexpr uint32_t kWideNone = 0xffffffffu;     //   a node number, or kWideNone for an empty child
+constexpr float kWideMaxDir = 2.f;              // longest ray direction the wide tree's padding is computed for
 
 // Everything a wavefront kernel needs, passed by value.  The slot pool is cut
 // into groups that run their wavefront steps on different HIP streams, so that
@@ -139,6 +150,8 @@ void launch_arith(hipStream_t s, int op, const float *x, const float *y, float *
 // 2 division-based box test, 3 reference node layout); measurement only
 void launch_variant(hipStream_t s, int variant, const TreeRef &tree, const float4 *reference_nodes, const float *soa_nodes,
                     uint32_t n_pairs, const float *rays, uint64_t n, rta_hit *hits, int depth);
+// certified traversal of the wide tree over a device-resident batch, then the exact traversal for the rays left in doubt
+void launch_wide_batch(hipStream_t s, const TreeRef &tree, const float *rays, uint64_t n, rta_hit *hits, int depth);
 void launch_pairs_to_soa(hipStream_t s, const float4 *pairs, uint32_t n_pairs, float *soa);
 
 }  // namespace rta

@@ -264,7 +264,7 @@ struct Traversal {
 	RTA_DEV void step(const DeviceTree &tree, uint32_t *stack, const int depth, WorkCount &work)
 	{
 		const bool leaf = at_prim();
-		const float4 *rec = leaf ? tree.prims + 3 * (size_t)(node & ~kLeafBit) : tree.pairs + 4 * (size_t)node;
+		const float4 *rec = leaf ? tree.prims + kPrimQuads * (size_t)(node & ~kLeafBit) : tree.pairs + 4 * (size_t)node;
 		const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
 		// keep the three loads whole (a primitive does not use q1.w and q2.w; loading
 		// them apart for nodes would cost a fifth instruction)
@@ -278,7 +278,7 @@ struct Traversal {
 	// Precondition: more && at_prim()
 	RTA_DEV void test_prim(const DeviceTree &tree, uint32_t *stack, WorkCount &work)
 	{
-		const float4 *rec = tree.prims + 3 * (size_t)(node & ~kLeafBit);
+		const float4 *rec = tree.prims + kPrimQuads * (size_t)(node & ~kLeafBit);
 		prim_unit(rec[0], rec[1], rec[2], stack, work);
 	}
 

@@ -1,0 +1,332 @@
+// Certified closest hit over the 4-wide tree (wide_tree.hpp).
+//
+// The reference's NearestHit (src/main.cpp:332-422) defines the result: the
+// nearest primitive among those it tests, the first-tested one on equal
+// distances.  What it tests depends on its visit order and on the rounding of
+// its box tests, so a traversal in another order over another tree cannot in
+// general be shown to return the same primitive - but for almost every ray it
+// can be shown AFTER the fact.  The traversal below walks the wide tree in any
+// order with approximate, conservative box tests, tests triangles with the
+// reference's own arithmetic (test_triangle), and ends with a candidate (w, F).
+// Let P be the set of triangles that HitTriangle accepts for this ray.
+//
+//   1. Conservative boxes (see wide_tree.cpp): every p in P with t_p <= F has
+//      all its wide-tree boxes entered before best (1 + 2^-20) >= F (1 + 2^-20)
+//      and left after 0, so the walk tests it.  Hence if the walk saw exactly
+//      one triangle with t <= F (no tie), w is the only member of P that near.
+//   2. The reference tests a subset of P's candidates, all others farther than
+//      F, so its running minimum never drops below F before it tests w.
+//   3. It does test w if the box of w's leaf passes ITS test with tmin < F
+//      (evaluated here with the reference's arithmetic, test_box_tame): boxes of
+//      the reference tree are nested and the slab quotients are monotonic in
+//      the planes, so every ancestor of the leaf passes with tmin <= the
+//      leaf's < F <= the running minimum (the builder checks the nesting).
+//
+// 1-3 give NearestHit = (w, F) with w's own t, u, v.  A miss of the walk means
+// P is empty.  Rays for which a step fails (a tie, the leaf's box not passed
+// with tmin < F, rays outside the range the padding was computed for, no room
+// left in the lane's LDS column) are "in doubt" and are traced again by the
+// exact traversal (traverse.hpp); nothing is ever answered from an unproven
+// candidate.
+//
+// Because the order is free, a lane that reaches a triangle does not test it at
+// once: it notes it in a list and goes on with the next node, and the wave runs
+// the (long) triangle test only when enough lanes have one waiting.  The list
+// shares the lane's LDS column with the node stack: stack entries grow from the
+// bottom, list entries from the top.
+#pragma once
+
+#include "traverse.hpp"
+
+namespace rta {
+
+template <bool COUNT, int STRIDE = kBlock>
+struct WideTraversal {
+	Ray ray;
+	V3 rcp, off;         // correctly rounded 1/direction; -(origin - scene centre) * rcp
+	uint32_t negative;   // bit k: direction component k is negative
+	float best;
+	int32_t prim;
+	float u, v;
+	uint32_t tie;        // another triangle at exactly `best`
+	uint32_t doubt;      // the exact traversal must answer this ray
+	uint32_t node;       // wide node to visit next, or kWideNone
+	int sp, lp;          // stack entries [0, sp), list entries [lp, cap)
+
+	RTA_DEV void rest(const int cap)
+	{
+		ray = Ray{mk(0, 0, 0), mk(1, 1, 1)};
+		rcp = mk(1, 1, 1);
+		off = mk(0, 0, 0);
+		negative = 0;
+		best = FLT_MAX;
+		prim = -1;
+		u = v = 0.f;
+		tie = doubt = false;
+		node = kWideNone;
+		sp = 0;
+		lp = cap;
+	}
+
+	RTA_DEV void start(const DeviceTree &tree, const Ray &r, const int cap)
+	{
+		ray = r;
+		rcp = mk(1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z);
+		const V3 from = r.o - mk(tree.wide_center[0], tree.wide_center[1], tree.wide_center[2]);
+		off = mk(-(from.x * rcp.x), -(from.y * rcp.y), -(from.z * rcp.z));
+		negative = (__float_as_uint(r.d.x) >> 31) | ((__float_as_uint(r.d.y) >> 31) << 1) | ((__float_as_uint(r.d.z) >> 31) << 2);
+		best = FLT_MAX;
+		prim = -1;
+		u = v = 0.f;
+		tie = false;
+		sp = 0;
+		lp = cap;
+		// the rays the wide tree's padding covers; NaNs fail the comparisons
+		const bool admitted =
+		    ray_is_tame(r) && norm2(r.d) <= kWideMaxDir * kWideMaxDir * (1.f - 0x1p-20f) && norm2(from) <= tree.wide_reach2;
+		doubt = !admitted;
+		node = admitted ? 0u : kWideNone;
+	}
+
+	RTA_DEV bool busy(const int cap) const { return node != kWideNone || sp > 0 || lp < cap; }
+	RTA_DEV bool has_node() const { return node != kWideNone || sp > 0; }
+	RTA_DEV bool has_list(const int cap) const { return lp < cap; }
+	// a visit files up to four references
+	RTA_DEV bool has_room() const { return lp - sp >= 4; }
+
+	RTA_DEV void give_up(const int cap)
+	{
+		doubt = true;
+		node = kWideNone;
+		sp = 0;
+		lp = cap;
+	}
+
+	// Precondition: node != kWideNone && has_room()
+	//
+	// A child's key is its reference (bit 31: triangle; 23 bits of node or primitive
+	// number) with 8 bits of the distance at which the ray enters its box in between,
+	// or all ones for a miss.  Sorted as unsigned numbers the four keys come out as
+	// nodes nearest first, then triangles nearest first, then misses, and the keys are
+	// at once the stack and list entries (see entry_lower_bound).
+	RTA_DEV void visit(const DeviceTree &tree, uint32_t *stack, WorkCount &work)
+	{
+		if (COUNT) work.inner++;
+		const bool sx = (negative & 1u) != 0, sy = (negative & 2u) != 0, sz = (negative & 4u) != 0;
+		// The record: 12 words of binary16 planes, two children per word (children 0,1 then 2,3),
+		// in the order lo.x lo.y lo.z hi.x hi.y hi.z, relative to the scene's centre; then the four
+		// references.  v_fma_mix_f32 reads a binary16 half as an operand, so nothing is converted.
+		typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+		const uint4 *rec = reinterpret_cast<const uint4 *>(tree.wide) + 4 * (size_t)node;
+		const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], refs = rec[3];
+		const uint32_t nx01 = sx ? q1.z : q0.x, nx23 = sx ? q1.w : q0.y, fx01 = sx ? q0.x : q1.z, fx23 = sx ? q0.y : q1.w;
+		const uint32_t ny01 = sy ? q2.x : q0.z, ny23 = sy ? q2.y : q0.w, fy01 = sy ? q0.z : q2.x, fy23 = sy ? q0.w : q2.y;
+		const uint32_t nz01 = sz ? q2.z : q1.x, nz23 = sz ? q2.w : q1.y, fz01 = sz ? q1.x : q2.z, fz23 = sz ? q1.y : q2.w;
+		const float reach = best * (1.f + 0x1p-20f);      // +inf while nothing is hit
+		uint32_t key[4];
+#define RTA_WIDE_HALF(word, part) ((float)__builtin_bit_cast(h2, word).part)
+#define RTA_WIDE_CHILD(s, pair, part, ref)                                                        \
+	{                                                                                             \
+		const float ex = __builtin_fmaf(RTA_WIDE_HALF(nx##pair, part), rcp.x, off.x);             \
+		const float ey = __builtin_fmaf(RTA_WIDE_HALF(ny##pair, part), rcp.y, off.y);             \
+		const float ez = __builtin_fmaf(RTA_WIDE_HALF(nz##pair, part), rcp.z, off.z);             \
+		const float xx = __builtin_fmaf(RTA_WIDE_HALF(fx##pair, part), rcp.x, off.x);             \
+		const float xy = __builtin_fmaf(RTA_WIDE_HALF(fy##pair, part), rcp.y, off.y);             \
+		const float xz = __builtin_fmaf(RTA_WIDE_HALF(fz##pair, part), rcp.z, off.z);             \
+		const float t0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(ex, ey), ez), 0.f);      \
+		const float t1 = __builtin_fminf(__builtin_fminf(__builtin_fminf(xx, xy), xz), reach);    \
+		key[s] = t0 <= t1 ? (ref | entry_distance(t0)) : 0xffffffffu;                             \
+	}
+		RTA_WIDE_CHILD(0, 01, x, refs.x)
+		RTA_WIDE_CHILD(1, 01, y, refs.y)
+		RTA_WIDE_CHILD(2, 23, x, refs.z)
+		RTA_WIDE_CHILD(3, 23, y, refs.w)
+#undef RTA_WIDE_CHILD
+#undef RTA_WIDE_HALF
+#define RTA_WIDE_SORT(a, b)                                         \
+	{                                                               \
+		const uint32_t lo_ = key[a] < key[b] ? key[a] : key[b];     \
+		const uint32_t hi_ = key[a] < key[b] ? key[b] : key[a];     \
+		key[a] = lo_;                                               \
+		key[b] = hi_;                                               \
+	}
+		RTA_WIDE_SORT(0, 1)
+		RTA_WIDE_SORT(2, 3)
+		RTA_WIDE_SORT(0, 2)
+		RTA_WIDE_SORT(1, 3)
+		RTA_WIDE_SORT(1, 2)
+#undef RTA_WIDE_SORT
+		// The nearest node is visited next; the other nodes go on the stack and the triangles
+		// on the list, the farthest first.  Nodes come first in the order, so key[i] being a
+		// node means that key[0] is one too.
+		node = (int32_t)key[0] >= 0 ? (key[0] & kEntryIndex) : kWideNone;
+#pragma unroll
+		for (int i = 3; i >= 1; i--)
+			if ((int32_t)key[i] >= 0) {
+				stack[sp * STRIDE] = key[i];
+				sp++;
+			}
+#pragma unroll
+		for (int i = 3; i >= 0; i--)
+			if ((int32_t)key[i] < 0 && key[i] != 0xffffffffu) {
+				lp--;
+				stack[lp * STRIDE] = key[i];
+			}
+	}
+
+	// Stack and list entries are the keys of visit(): bits 23-30 hold the distance at
+	// which the ray enters the box, rounded DOWN to 5 exponent bits (2^-16 .. 2^15)
+	// and 3 significand bits; an entry is dropped when it comes up and even that lower
+	// bound lies beyond the nearest hit so far.
+	static constexpr uint32_t kEntryIndex = 0x007fffffu;
+	// t >= 0
+	RTA_DEV static uint32_t entry_distance(float t)
+	{
+		const uint32_t top = __float_as_uint(t) >> 20;     // 8 exponent bits, 3 significand bits
+		const uint32_t q = top < 888u ? 0u : (top - 888u < 255u ? top - 888u : 255u);      // 888 = 111 << 3: 2^-16
+		return q << 23;
+	}
+	RTA_DEV static float entry_lower_bound(uint32_t entry)
+	{
+		const uint32_t q = (entry >> 23) & 0xffu;
+		return q ? __uint_as_float((q + 888u) << 20) : 0.f;
+	}
+
+	// the next node from the stack whose box the ray may still have to enter (at most two tries per trip)
+	RTA_DEV void take_node(uint32_t *stack)
+	{
+		const float reach = best * (1.f + 0x1p-20f);
+#pragma unroll
+		for (int k = 0; k < 2; k++)
+			if (node == kWideNone && sp > 0) {
+				const uint32_t e = stack[(--sp) * STRIDE];
+				if (entry_lower_bound(e) <= reach)
+					node = e & kEntryIndex;
+			}
+	}
+
+	// Precondition: has_list(cap)
+	RTA_DEV void test_listed(const DeviceTree &tree, uint32_t *stack, const int cap, WorkCount &work)
+	{
+		const float reach = best * (1.f + 0x1p-20f);
+		uint32_t e = stack[lp * STRIDE];
+		lp++;
+		if (entry_lower_bound(e) > reach) {
+			if (lp >= cap)
+				return;
+			e = stack[lp * STRIDE];
+			lp++;
+			if (entry_lower_bound(e) > reach)
+				return;
+		}
+		if (COUNT) work.tri++;
+		const uint32_t i = e & kEntryIndex;
+		const float4 *rec = tree.prims + kPrimQuads * (size_t)i;
+		const float4 p0 = rec[0], p1 = rec[1], p2 = rec[2];
+		float tu = 0, tv = 0;
+		const float t = test_triangle(mk(p0.x, p0.y, p0.z), mk(p1.x, p1.y, p1.z), mk(p2.x, p2.y, p2.z), ray, tu, tv);
+		if (t < best) {
+			best = t;
+			prim = (int32_t)i;
+			u = tu;
+			v = tv;
+			tie = false;
+		} else if (t == best && t < FLT_MAX) {
+			tie = true;
+		}
+	}
+
+	// Steps 2 and 3 of the proof for a finished walk.
+	RTA_DEV void certify(const DeviceTree &tree)
+	{
+		if (doubt || prim < 0)
+			return;
+		if (tie) {
+			doubt = true;
+			return;
+		}
+		const float4 b0 = tree.leaf_boxes[2 * (size_t)prim], b1 = tree.leaf_boxes[2 * (size_t)prim + 1];
+		const float d = test_box_tame(mk(b0.x, b0.y, b0.z), mk(b1.x, b1.y, b1.z), ray, rcp, best);
+		doubt = !(d < FLT_MAX);
+	}
+
+	RTA_DEV HitRec result() const { return HitRec{prim, best, u, v}; }
+};
+
+// A wave works through more rays than it has lanes (as traverse_pulling).
+//   got = grab(want, first)                  reserves up to `want` rays
+//   tag = load(i, ray)                       fetches ray number i
+//   store(finished, tag, hit, doubt)         called by ALL lanes of the wave together; `finished` lanes
+//                                            hand in their ray's result, or `doubt`: trace it exactly
+// `quorum`: lanes with a listed triangle that make the wave run the triangle test.
+// per lane; lane 0's trips and runs are the wave's
+struct WideCensus {
+	uint32_t trips, visit_runs, visit_lanes, test_runs, test_lanes;
+};
+
+template <bool COUNT, class Grab, class Load, class Store>
+RTA_DEV void traverse_wide_pulling(const DeviceTree &tree, const uint32_t refill_at, const uint32_t quorum, uint32_t *stack,
+                                   const int cap, WorkCount &work, WideCensus &census, Grab grab, Load load, Store store)
+{
+	WideTraversal<COUNT> tr;
+	tr.rest(cap);
+	uint32_t tag = 0;
+	bool loaded = false, dry = false;
+	for (;;) {
+		const unsigned long long idle = __ballot(!tr.busy(cap));
+		const uint32_t n_idle = (uint32_t)__popcll(idle);
+		if (!dry && n_idle >= refill_at) {
+			const bool finished = loaded && !tr.busy(cap);
+			if (finished)
+				tr.certify(tree);
+			store(finished, tag, tr.result(), tr.doubt != 0);
+			if (finished)
+				loaded = false;
+			uint32_t first = 0;
+			const uint32_t got = grab(n_idle, first);
+			dry = got < n_idle;
+			const uint32_t rank =
+			    __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+			if (!tr.busy(cap) && rank < got) {
+				Ray ray;
+				tag = load(first + rank, ray);
+				tr.start(tree, ray, cap);
+				loaded = true;
+			}
+		}
+		if (__ballot(tr.busy(cap)) == 0) {
+			if (dry)
+				break;
+			// lanes whose rays were not admitted are through at once: the next trip hands them on
+			continue;
+		}
+		// a lane whose column is full cannot visit; it waits for the triangle test to shorten
+		// its list, and gives the ray up if there is no list to shorten
+		if (tr.has_node() && !tr.has_room() && !tr.has_list(cap))
+			tr.give_up(cap);
+		const bool can_visit = tr.has_node() && tr.has_room();
+		const bool listed = tr.has_list(cap);
+		const uint32_t n_visit = (uint32_t)__popcll(__ballot(can_visit));
+		const uint32_t n_listed = (uint32_t)__popcll(__ballot(listed));
+		if (COUNT) census.trips++;
+		if (n_listed >= quorum || n_visit == 0 || __ballot(tr.has_node() && !tr.has_room())) {
+			if (COUNT) census.test_runs++, census.test_lanes += listed;
+			if (listed)
+				tr.test_listed(tree, stack, cap, work);
+		}
+		if (n_visit) {
+			if (COUNT) census.visit_runs++, census.visit_lanes += can_visit;
+			if (can_visit) {
+				tr.take_node(stack);
+				if (tr.node != kWideNone)
+					tr.visit(tree, stack, work);
+			}
+		}
+	}
+	// the last rays
+	if (loaded)
+		tr.certify(tree);
+	store(loaded, tag, tr.result(), tr.doubt != 0);
+}
+
+}  // namespace rta

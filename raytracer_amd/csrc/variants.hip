@@ -24,8 +24,11 @@
 //   200 + d    as 101 with the LDS stack sized for d entries: fewer workgroups
 //              per CU, i.e. what occupancy is worth (d >= the tree's depth)
 
+#include <cstdlib>
+
 #include "kernels.hpp"
 #include "traverse.hpp"
+#include "traverse_wide.hpp"
 
 namespace rta {
 
@@ -92,12 +95,12 @@ __global__ __launch_bounds__(kBlock) void k_variant_reference_nodes(const Device
 		const int32_t index = __float_as_int(me.z), count = __float_as_int(me.w);
 		if (count > 0) {
 			for (int32_t k = index; k < index + count; k++) {
-				const float4 p0 = tree.prims[3 * (size_t)k], p1 = tree.prims[3 * (size_t)k + 1];
+				const float4 p0 = tree.prims[kPrimQuads * (size_t)k], p1 = tree.prims[kPrimQuads * (size_t)k + 1];
 				float t, tu = 0, tv = 0;
 				if (__float_as_uint(p0.w) & kPrimSphere) {
 					t = test_sphere(mk(p0.x, p0.y, p0.z), p1.x, ray);
 				} else {
-					const float4 p2 = tree.prims[3 * (size_t)k + 2];
+					const float4 p2 = tree.prims[kPrimQuads * (size_t)k + 2];
 					t = test_triangle(mk(p0.x, p0.y, p0.z), mk(p1.x, p1.y, p1.z), mk(p2.x, p2.y, p2.z), ray, tu, tv);
 				}
 				if (t < best) {
@@ -194,13 +197,13 @@ __global__ __launch_bounds__(kBlock) void k_variant_nested_loops(const DeviceTre
 			break;
 		uint32_t k = node & ~kLeafBit;
 		for (;;) {
-			const float4 p0 = tree.prims[3 * (size_t)k], p1 = tree.prims[3 * (size_t)k + 1];
+			const float4 p0 = tree.prims[kPrimQuads * (size_t)k], p1 = tree.prims[kPrimQuads * (size_t)k + 1];
 			const uint32_t flags = __float_as_uint(p0.w);
 			float t, tu = 0, tv = 0;
 			if (flags & kPrimSphere) {
 				t = test_sphere(mk(p0.x, p0.y, p0.z), p1.x, ray);
 			} else {
-				const float4 p2 = tree.prims[3 * (size_t)k + 2];
+				const float4 p2 = tree.prims[kPrimQuads * (size_t)k + 2];
 				t = test_triangle(mk(p0.x, p0.y, p0.z), mk(p1.x, p1.y, p1.z), mk(p2.x, p2.y, p2.z), ray, tu, tv);
 			}
 			if (t < best) {
@@ -302,7 +305,111 @@ __global__ __launch_bounds__(kBlock) void k_variant_threshold(const DeviceTree t
 		hits[i] = rta_hit{h.prim, h.t, h.u, h.v};
 }
 
+// Certified traversal of the wide tree; a ray left in doubt gets prim = -2 and is
+// answered by k_wide_redo.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_wide_batch(
+    const DeviceTree tree, const float *rays, uint64_t n, rta_hit *hits, const int cap, const uint32_t rays_per_lane,
+    const uint32_t refill_at, const uint32_t quorum, unsigned long long *census)
+{
+	extern __shared__ uint32_t lds_stack[];
+	const uint64_t per_wave = 64 * (uint64_t)rays_per_lane;
+	const uint64_t begin = ((uint64_t)blockIdx.x * (kBlock / 64) + threadIdx.x / 64) * per_wave;
+	WorkCount wc = {0, 0, 0};
+	WideCensus cs = {0, 0, 0, 0, 0};
+	if (begin < n) {
+		const float *mine = rays + begin * 6;
+		rta_hit *out = hits + begin;
+		traverse_wide_pulling<COUNT>(
+		    tree, refill_at, quorum, lds_stack + threadIdx.x, cap, wc, cs,
+		    OwnChunk{(uint32_t)(n - begin < per_wave ? n - begin : per_wave), 0u},
+		    [&](uint32_t i, Ray &ray) {
+			    const float *r = mine + (size_t)i * 6;
+			    ray = Ray{mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5])};
+			    return i;
+		    },
+		    [&](bool finished, uint32_t i, const HitRec &h, bool doubt) {
+			    if (finished)
+				    out[i] = doubt ? rta_hit{-2, 0.f, 0.f, 0.f} : rta_hit{h.prim, h.t, h.u, h.v};
+			    if (COUNT && finished && doubt)
+				    wc.sph++;
+		    });
+	}
+	if (COUNT) {
+		if (wc.inner) atomicAdd(&census[0], (unsigned long long)wc.inner);
+		if (wc.tri) atomicAdd(&census[1], (unsigned long long)wc.tri);
+		if (wc.sph) atomicAdd(&census[2], (unsigned long long)wc.sph);
+		if ((threadIdx.x & 63) == 0) {
+			atomicAdd(&census[3], (unsigned long long)cs.trips);
+			atomicAdd(&census[4], (unsigned long long)cs.visit_runs);
+			atomicAdd(&census[6], (unsigned long long)cs.test_runs);
+		}
+		if (cs.visit_lanes) atomicAdd(&census[5], (unsigned long long)cs.visit_lanes);
+		if (cs.test_lanes) atomicAdd(&census[7], (unsigned long long)cs.test_lanes);
+	}
+}
+
+__global__ __launch_bounds__(kBlock) void k_wide_redo(const DeviceTree tree, const float *rays, uint64_t n, rta_hit *hits,
+                                                      const int depth)
+{
+	extern __shared__ uint32_t lds_stack[];
+	const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+	const bool mine = i < n && hits[i].prim == -2;
+	if (__ballot(mine) == 0)
+		return;
+	Traversal<false, false> tr;
+	WorkCount wc = {0, 0, 0};
+	tr.rest();
+	if (mine) {
+		const float *r = rays + i * 6;
+		tr.start(tree, Ray{mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5])}, FLT_MAX);
+	}
+	while (__ballot(tr.more)) {
+		if (tr.more)
+			tr.step(tree, lds_stack + threadIdx.x, depth, wc);
+	}
+	if (mine) {
+		const HitRec h = tr.result();
+		hits[i] = rta_hit{h.prim, h.t, h.u, h.v};
+	}
+}
+
 }  // namespace
+
+static int env_int(const char *name, int fallback)
+{
+	const char *v = getenv(name);
+	return v && *v ? atoi(v) : fallback;
+}
+
+void launch_wide_batch(hipStream_t s, const TreeRef &tree, const float *rays, uint64_t n, rta_hit *hits, int depth)
+{
+	const int cap = env_int("RTA_WIDE_CAP", 20), rpl = env_int("RTA_WIDE_RPL", 8), refill = env_int("RTA_WIDE_REFILL", 24),
+	          quorum = env_int("RTA_WIDE_QUORUM", 24), count = env_int("RTA_WIDE_COUNT", 0);
+	const uint64_t per_block = (uint64_t)kBlock * (uint64_t)rpl;
+	const unsigned blocks = (unsigned)((n + per_block - 1) / per_block);
+	const size_t lds = (size_t)cap * kBlock * sizeof(uint32_t);
+	if (count) {
+		unsigned long long *census = nullptr, host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+		(void)hipMalloc((void **)&census, sizeof host);
+		(void)hipMemsetAsync(census, 0, sizeof host, s);
+		hipLaunchKernelGGL(k_wide_batch<true>, dim3(blocks), dim3(kBlock), lds, s, tree, rays, n, hits, cap, (uint32_t)rpl,
+		                   (uint32_t)refill, (uint32_t)quorum, census);
+		(void)hipMemcpyAsync(host, census, sizeof host, hipMemcpyDeviceToHost, s);
+		(void)hipStreamSynchronize(s);
+		(void)hipFree(census);
+		fprintf(stderr, "wide: %.2f node visits, %.2f triangle tests per ray, %llu of %llu rays in doubt; per 64 rays %.1f trips, "
+		        "%.1f visit runs (%.1f lanes), %.1f test runs (%.1f lanes)\n",
+		        (double)host[0] / (double)n, (double)host[1] / (double)n, host[2], (unsigned long long)n,
+		        (double)host[3] * 64 / (double)n, (double)host[4] * 64 / (double)n, (double)host[5] / (double)(host[4] ? host[4] : 1),
+		        (double)host[6] * 64 / (double)n, (double)host[7] / (double)(host[6] ? host[6] : 1));
+	} else {
+		hipLaunchKernelGGL(k_wide_batch<false>, dim3(blocks), dim3(kBlock), lds, s, tree, rays, n, hits, cap, (uint32_t)rpl,
+		                   (uint32_t)refill, (uint32_t)quorum, (unsigned long long *)nullptr);
+	}
+	hipLaunchKernelGGL(k_wide_redo, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock),
+	                   (size_t)depth * kBlock * sizeof(uint32_t), s, tree, rays, n, hits, depth);
+}
 
 void launch_pairs_to_soa(hipStream_t s, const float4 *pairs, uint32_t n_pairs, float *soa)
 {

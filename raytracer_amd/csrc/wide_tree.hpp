@@ -1,0 +1,43 @@
+// A second, 4-wide tree over the same primitives for the certified traversal
+// (traverse_wide.hpp).  Built on the host at upload from the scene description;
+// the reference's own tree (src/main.cpp:170-248) stays the one that defines
+// every result.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+#include "raytracer_amd.h"
+
+namespace rta {
+
+struct WideTree {
+	bool enabled = false;
+	std::string why_not;              // when !enabled
+	// 4 x 16 bytes per node (one 64-byte line): twelve words of binary16 planes of the four
+	// children, relative to `center` and rounded outwards (lo.x lo.y lo.z hi.x hi.y hi.z, each as
+	// two words: children 0,1 and children 2,3), then the four child references.  A reference is
+	// a node number, kWideLeaf | primitive, or kWideNone; an empty child's box is inverted
+	// (lo = +inf, hi = -inf).
+	std::vector<float4> nodes;
+	// 2 x 16 bytes per primitive: the box of its leaf in the reference's tree (lo, hi)
+	std::vector<float4> leaf_boxes;
+	float center[3] = {0, 0, 0};      // rays may take the wide tree when |origin - center| <= reach
+	float reach = 0;                  //   and |direction| <= kWideMaxDir
+	int depth = 0;                    // levels of wide nodes
+	uint32_t n_nodes = 0;
+	double mean_pad_over_extent = 0;  // diagnostic: padding relative to the padded child boxes' mean extent
+};
+
+// reach + scene radius, in scene radii: rays that start inside the sphere around the scene's box (bounce
+// rays do) are admitted; the padding grows with this number
+constexpr float kWideReachRadii = 2.05f;
+
+// `tame`: every box coordinate of the reference's tree is ordinary (see ray_is_tame)
+WideTree build_wide_tree(const rta_scene_desc &d, bool tame);
+
+}  // namespace rta

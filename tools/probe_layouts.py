@@ -44,7 +44,7 @@ def main():
     p = prim[hit, 0:3] + prim[hit, 3:6] * first["t"][hit, None]
     d = rng.standard_normal((p.shape[0], 3)).astype(np.float32)
     d /= np.linalg.norm(d, axis=1, keepdims=True)
-    bounce = np.tile(np.concatenate([p, d], axis=1).astype(np.float32), (8, 1))
+    bounce = np.tile(np.concatenate([p, d], axis=1).astype(np.float32), (int(os.environ.get("COPIES", "8")), 1))
     sets = {"camera rays 1080p": prim, "bounce rays x8": bounce}
     if os.environ.get("OCTANT"):
         # the same bounce rays, runs of OCTANT consecutive ones ordered by direction octant

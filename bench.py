@@ -145,6 +145,8 @@ def main():
     ap.add_argument("--slots", type=int, default=0)
     ap.add_argument("--run-blocks", type=int, default=0)
     ap.add_argument("--streams", type=int, default=0)
+    ap.add_argument("--exact-only", action="store_true",
+                    help="every ray through the order-replaying traversal (RTA_RENDER_EXACT_ONLY), to price the certified walk")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the two extra renders behind `roofline`")
     args = ap.parse_args()
@@ -196,6 +198,8 @@ def main():
     by_samples = args.sharding == "samples" and world > 1
 
     def params(spp, flags=0, streams=None):
+        if args.exact_only:
+            flags |= rta.RENDER_EXACT_ONLY
         p = rta.RenderParams(width=width, height=height, samples=spp, exposure=s.exposure, seed=69420,
                              samples_per_stream=args.samples_per_stream, shard_index=rank, shard_count=world,
                              slots=args.slots, out_mem=rta.MEM_DEVICE, run_blocks=args.run_blocks,
@@ -246,7 +250,7 @@ def main():
         elapsed = time.perf_counter() - t0
         tot = {k: sum(st[k] for st in stats) for k in stats[0]}
         v = torch.tensor([elapsed, float(tot["rays"] + tot["shadow_rays"]), float(tot["samples"]),
-                          float(tot["rays"] - tot["early_rays"] + tot["shadow_rays"]), tot["gpu_ms"]],
+                          float(tot["rays"] - tot["early_rays"] + tot["shadow_rays"]), tot["gpu_ms"], float(tot["retraced_rays"])],
                          dtype=torch.float64, device=dev)
         if dist is not None:
             mx = v.clone()
@@ -254,9 +258,9 @@ def main():
             sm = v.clone()
             dist.all_reduce(sm, op=dist.ReduceOp.SUM)
             return dict(elapsed=float(mx[0]), queries=float(sm[1]), samples=float(sm[2]), traced=float(sm[3]),
-                        gpu_ms_max=float(mx[4]), spp=spp)
+                        gpu_ms_max=float(mx[4]), spp=spp, retraced=float(sm[5]))
         return dict(elapsed=float(v[0]), queries=float(v[1]), samples=float(v[2]), traced=float(v[3]),
-                    gpu_ms_max=float(v[4]), spp=spp)
+                    gpu_ms_max=float(v[4]), spp=spp, retraced=float(v[5]))
 
     spp_weak = spp_fixed * world
     main_run = run(spp_weak if args.scaling == "weak" else spp_fixed)
@@ -300,6 +304,8 @@ def main():
                             "Occluded call); traced_mrays_per_s counts only those that walked the tree",
             "traced_mrays_per_s": m["traced_mrays_per_s"],
             "traced_fraction": main_run["traced"] / main_run["queries"],
+            "retraced_rays_per_step": main_run["retraced"] / args.steps,
+            "traversal": "exact only" if args.exact_only else "certified walk over the wide tree for bounce rays, exact for the rest",
             "samples_per_s": m["samples_per_s"],
             "n_gpus": world,
             "steps": args.steps,

@@ -224,7 +224,10 @@ typedef struct {
 enum {
 	RTA_RENDER_TIME_KERNELS = 1,   /* bracket every advance, shadow and intersect launch with HIP events (stats.*_ms) */
 	RTA_RENDER_COUNT_WORK = 2,     /* count node visits / primitive tests (slower kernels) */
-	RTA_RENDER_SMALL_PASSES = 4    /* hold as few sample blocks in memory at a time as possible (see rta_render) */
+	RTA_RENDER_SMALL_PASSES = 4,   /* hold as few sample blocks in memory at a time as possible (see rta_render) */
+	RTA_RENDER_EXACT_ONLY = 8      /* every ray through the traversal that replays the reference's visit order; without it
+	                                * bounce rays of triangle scenes walk a second, 4-wide tree in any order and are answered
+	                                * from that walk only where it proves NearestHit's result (same bits either way) */
 };
 
 typedef struct {
@@ -240,6 +243,9 @@ typedef struct {
 	                                         * is the number of closest-hit queries that walked the tree */
 	double advance_ms;                      /* RTA_RENDER_TIME_KERNELS only: summed durations of the advance launches */
 	uint64_t advance_launches;
+	uint64_t retraced_rays;                 /* of `rays`: bounce rays whose walk over the wide tree could not prove its
+	                                         * answer (an exact tie, a hit on the rim of its leaf's box, ...) and that the
+	                                         * order-replaying traversal answered instead */
 } rta_stats;
 
 /* The render loop.  Replaces src/main.cpp:657-714 (row loop, per-sample ray

@@ -19,7 +19,7 @@ CLI_PATH = os.path.join(_HERE, "raytracer")
 
 MEM_HOST, MEM_DEVICE = 0, 1
 PRIM_TRIANGLE, PRIM_SPHERE = 0, 1
-RENDER_TIME_KERNELS, RENDER_COUNT_WORK, RENDER_SMALL_PASSES = 1, 2, 4
+RENDER_TIME_KERNELS, RENDER_COUNT_WORK, RENDER_SMALL_PASSES, RENDER_EXACT_ONLY = 1, 2, 4, 8
 STATIC_MAX_RAYS = 1 << 20
 
 OK = 0
@@ -68,7 +68,8 @@ class Stats(C.Structure):
                 ("inner_visits", C.c_uint64), ("tri_tests", C.c_uint64), ("sph_tests", C.c_uint64),
                 ("gpu_ms", C.c_double), ("intersect_ms", C.c_double), ("shadow_ms", C.c_double),
                 ("intersect_launches", C.c_uint64), ("shadow_launches", C.c_uint64),
-                ("early_rays", C.c_uint64), ("advance_ms", C.c_double), ("advance_launches", C.c_uint64)]
+                ("early_rays", C.c_uint64), ("advance_ms", C.c_double), ("advance_launches", C.c_uint64),
+                ("retraced_rays", C.c_uint64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

@@ -130,6 +130,7 @@ TreeRef tree_of(const rta_context *ctx)
 	t.leaf_boxes = ctx->leaf_boxes.as<const float4>();
 	memcpy(t.wide_center, ctx->wide_center, 12);
 	t.wide_reach2 = ctx->wide_reach2;
+	t.wide_index_mask = ctx->wide_index_mask;
 	return t;
 }
 
@@ -437,6 +438,7 @@ int rta_upload_scene(rta_context *ctx, const rta_scene_desc *desc)
 		memcpy(ctx->wide_center, wide.center, 12);
 		ctx->wide_reach2 = wide.reach * wide.reach * (1.f - 0x1p-20f);
 		ctx->wide_depth = wide.depth;
+		ctx->wide_index_mask = wide.index_mask;
 	}
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // the staging vectors die with this call
 	ctx->have_wide = wide.enabled;
@@ -796,6 +798,8 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	const uint32_t shard_cap = (uint32_t)((group_blocks + kShards - 1) / kShards) * 256;
 	const size_t group_queue = (size_t)2 * kRayKinds * kShards * shard_cap;
 	HIP_TRY(ctx, ctx->q_ray.reserve(group_queue * groups * 4));
+	const size_t group_bounce = (size_t)2 * kShards * shard_cap * 2;      // quads
+	HIP_TRY(ctx, ctx->q_bounce.reserve(group_bounce * groups * 16));
 	if (ctx->n_lights > 0)
 		HIP_TRY(ctx, ctx->shadow.reserve(S * 48));
 	// Block sums are kept until their pixel's earlier blocks are in, 16 bytes per
@@ -868,6 +872,9 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	}
 	// long leaves (4 primitives and more on average): see traverse_leafwise
 	base.leafwise = (uint64_t)ctx->n_prims >= 4 * ((uint64_t)ctx->n_pairs + 1) ? 1u : 0u;
+	// Bounce rays take the certified walk over the wide tree where the scene has one (triangles
+	// only, short leaves); 20 LDS entries per lane keep 8 workgroups on a CU
+	base.wide_cap = (ctx->have_wide && !base.leafwise && !(p->flags & RTA_RENDER_EXACT_ONLY)) ? 20u : 0u;
 	base.rays_per_lane = 8;       // measured on dragon.txt: 4 and 12 lose 1-2 %
 	base.refill_at = 24;          // likewise 16 (8 loses 3 %)
 
@@ -887,6 +894,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		a.meta = ctx->meta.as<uint4>() + off;
 		a.shadow = ctx->shadow.as<float4>() ? ctx->shadow.as<float4>() + 3 * off : nullptr;
 		a.q_ray = ctx->q_ray.as<uint32_t>() + (size_t)g * group_queue;
+		a.q_bounce = ctx->q_bounce.as<float4>() + (size_t)g * group_bounce;
 		a.shard_cap = shard_cap;
 		a.grid_cap = shard_cap;
 		a.cnt = ctx->counters.as<Counters>() + g;
@@ -1100,6 +1108,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 			st.inner_visits += c.inner;
 			st.tri_tests += c.tri;
 			st.sph_tests += c.sph;
+			st.retraced_rays += c.retraced;
 		}
 		// all groups are idle here (synchronised above)
 		if (d_frame && n_owned)

@@ -58,6 +58,7 @@ struct rta_context {
 	bool have_wide = false;
 	float wide_center[3] = {0, 0, 0}, wide_reach2 = 0;
 	int wide_depth = 0;
+	uint32_t wide_index_mask = 0;
 	rta::DeviceBuffer soa_nodes;      // variant 5 only, made from `pairs` on first use
 	uint32_t n_pairs = 0;
 	bool have_soa = false;
@@ -69,7 +70,7 @@ struct rta_context {
 	int32_t n_prims = 0, n_lights = 0;
 
 	// wavefront workspace
-	rta::DeviceBuffer ray0, ray1, hit, thr, col, rng, acc, meta, q_ray, shadow, partial, pixels, frame, bgr, counters;
+	rta::DeviceBuffer ray0, ray1, hit, thr, col, rng, acc, meta, q_ray, q_bounce, shadow, partial, pixels, frame, bgr, counters;
 	rta::DeviceBuffer part_weights, part_order;
 	rta::DeviceBuffer cover, sky_map;         // see k_sky_map
 	rta::DeviceBuffer ray_order;              // see tracing_order

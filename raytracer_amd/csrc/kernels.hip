@@ -38,8 +38,12 @@
 
 #include "kernels.hpp"
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "shading.hpp"
 #include "traverse.hpp"
+#include "traverse_wide.hpp"
 
 namespace rta {
 
@@ -52,8 +56,14 @@ constexpr uint32_t kEnded = 0xffffffffu;       // path finished, its occlusion q
 // k_sky_map values up to this say that no sample of the pixel can reach a leaf's box (u1 >= 2^-24 > this)
 constexpr float kNoSampleReaches = 0x1p-25f;
 // kinds of closest-hit rays, queued apart; kOddRays are the (rare) rays whose
-// box tests need the division-based form (see ray_is_tame), of either origin
-constexpr int kCameraRays = 0, kBounceRays = 1, kOddRays = 2;
+// box tests need the division-based form (see ray_is_tame), of either origin;
+// kDoubtRays are bounce rays whose certified walk over the wide tree could not
+// prove its answer (traverse_wide.hpp), queued by the traversal kernel itself for
+// the exact traversal that follows it
+constexpr int kCameraRays = 0, kBounceRays = 1, kOddRays = 2, kDoubtRays = 3;
+// certified walk: idle lanes that make a wave draw new rays, lanes with a listed triangle
+// (lanes with nothing else to do) that make it run the triangle test
+constexpr uint32_t kWideRefillAt = 16, kWideQuorum = 24, kWideWaiting = 16;
 
 RTA_DEV float4 f4(V3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
 RTA_DEV float4 f4u(V3 v, uint32_t w) { return make_float4(v.x, v.y, v.z, __uint_as_float(w)); }
@@ -95,8 +105,14 @@ RTA_DEV void ray_queue_push(const RenderArgs &a, int par, int kind, bool pred, u
 	const uint32_t shard = blockIdx.x % kShards;
 	const uint32_t q = ray_queue_index(par, kind, shard);
 	const uint32_t at = queue_push(pred && tame, &a.cnt->n_ray[q]);
-	if (pred && tame)
+	if (pred && tame) {
 		a.q_ray[(size_t)q * a.shard_cap + at] = slot;
+		if (kind == kBounceRays) {
+			float4 *e = a.q_bounce + 2 * (((size_t)par * kShards + shard) * a.shard_cap + at);
+			e[0] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.d.x);
+			e[1] = make_float4(ray.d.y, ray.d.z, __uint_as_float(slot), 0.f);
+		}
+	}
 	if (__ballot(pred && !tame)) {
 		const uint32_t qo = ray_queue_index(par, kOddRays, shard);
 		const uint32_t ato = queue_push(pred && !tame, &a.cnt->n_ray[qo]);
@@ -512,7 +528,8 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 RTA_DEV void step_housekeeping(const RenderArgs &a, int par)
 {
 	if (threadIdx.x < kRayKinds * kShards) {
-		const uint32_t n = a.cnt->n_ray[ray_queue_index(par, 0, 0) + threadIdx.x];
+		// (the queue of rays to trace again fills while this launch runs; its rays are counted already)
+		const uint32_t n = threadIdx.x < kDoubtRays * kShards ? a.cnt->n_ray[ray_queue_index(par, 0, 0) + threadIdx.x] : 0;
 		if (n)
 			atomicAdd(&a.cnt->rays, (unsigned long long)n);
 		a.cnt->n_ray[ray_queue_index(par ^ 1, 0, 0) + threadIdx.x] = 0;
@@ -538,14 +555,18 @@ RTA_DEV uint32_t pulling_blocks(uint32_t n_rays, uint32_t rpl) { return (n_rays 
 // host's bound on what a sub-queue can hold this step.
 RTA_DEV uint32_t pulling_grid(uint32_t shard_cap, uint32_t rpl) { return kShards * pulling_blocks(shard_cap, rpl); }
 
-template <bool COUNT>
+template <bool COUNT, bool WIDE, int PART = 0>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_intersect(const RenderArgs a, const int par, const int depth)
 {
 	extern __shared__ uint32_t lds_stack[];
-	if (blockIdx.x == 0)
+	if (blockIdx.x == 0 && PART != 2)
 		step_housekeeping(a, par);
 	WorkCount wc = {0, 0, 0};
 	const uint32_t n_pulling = pulling_grid(a.grid_cap, a.rays_per_lane);
+	if (PART == 1 && blockIdx.x >= n_pulling)
+		return;
+	if (PART == 2 && blockIdx.x < n_pulling)
+		return;
 	if (blockIdx.x < n_pulling) {
 		const uint32_t shard = blockIdx.x % kShards, part = blockIdx.x / kShards;
 		const uint32_t q = ray_queue_index(par, kBounceRays, shard);
@@ -555,16 +576,38 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 		const uint32_t spread = (total + 8 * kBlock - 1) / (8 * kBlock);
 		const uint32_t rays_per_lane = spread < a.rays_per_lane ? (spread ? spread : 1u) : a.rays_per_lane;
 		if (part < pulling_blocks(total, rays_per_lane)) {
-			const uint32_t *queue = a.q_ray + (size_t)q * a.shard_cap;
+			const float4 *queue = a.q_bounce + 2 * ((size_t)par * kShards + shard) * a.shard_cap;
+			if (WIDE) {
+				WideCensus census = {0, 0, 0, 0, 0};
+				const uint32_t qd = ray_queue_index(par, kDoubtRays, shard);
+				traverse_wide_pulling<COUNT>(
+				    a.tree, kWideRefillAt, kWideQuorum, kWideWaiting, lds_stack + threadIdx.x, (int)a.wide_cap, wc, census,
+				    SharedList{total, &a.cnt->head[(uint32_t)par * kShards + shard], 32u * rays_per_lane},
+				    [&](uint32_t i, Ray &ray) {
+					    const float4 r0 = queue[2 * (size_t)i], r1 = queue[2 * (size_t)i + 1];
+					    ray = Ray{mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y)};
+					    return __float_as_uint(r1.z);
+				    },
+				    [&](bool finished, uint32_t slot, const HitRec &h, bool doubt) {
+					    if (finished && !doubt)
+						    a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
+					    // a ray whose answer is not proven goes to the exact traversal (k_intersect_odd)
+					    const bool again = finished && doubt;
+					    if (__ballot(again)) {
+						    const uint32_t at = queue_push(again, &a.cnt->n_ray[qd]);
+						    if (again)
+							    a.q_ray[(size_t)qd * a.shard_cap + at] = slot;
+					    }
+				    });
+			} else
 			traverse_pulling<false, COUNT, true>(
 			    a.tree, a.refill_at, lds_stack + threadIdx.x, depth, wc,
-			    SharedList{total, &a.cnt->head[(uint32_t)par * kShards + shard]},
+			    SharedList{total, &a.cnt->head[(uint32_t)par * kShards + shard], 32u * rays_per_lane},
 			    [&](uint32_t i, Ray &ray, float &limit) {
-				    const uint32_t slot = queue[i];
-				    const float4 r0 = a.ray0[slot], r1 = a.ray1[slot];
+				    const float4 r0 = queue[2 * (size_t)i], r1 = queue[2 * (size_t)i + 1];
 				    ray = Ray{mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y)};
 				    limit = FLT_MAX;
-				    return slot;
+				    return __float_as_uint(r1.z);
 			    },
 			    [&](uint32_t slot, const HitRec &h) {
 				    a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
@@ -619,23 +662,29 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 		count_flush(a.cnt, wc);
 }
 
-// The rays that need the division-based box test.  Any grid that is a multiple
-// of kShards works: the workgroups of a shard stride over its sub-queue.
+// The rays that need the division-based box test, and the rays that the
+// certified walk of the launch before left to the exact traversal.  Any grid that
+// is a multiple of kShards works: the workgroups of a shard stride over its
+// sub-queues.
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_intersect_odd(const RenderArgs a, const int par, const int depth)
 {
 	extern __shared__ uint32_t lds_stack[];
 	const uint32_t shard = blockIdx.x % kShards, part = blockIdx.x / kShards, parts = gridDim.x / kShards;
-	const uint32_t q = ray_queue_index(par, kOddRays, shard);
-	const uint32_t total = a.cnt->n_ray[q];
 	WorkCount wc = {0, 0, 0};
-	for (uint32_t i = part * kBlock + threadIdx.x; i < total; i += parts * kBlock) {
-		const uint32_t slot = a.q_ray[(size_t)q * a.shard_cap + i];
-		const float4 r0 = a.ray0[slot], r1 = a.ray1[slot];
-		Ray ray = {mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y)};
-		HitRec h;
-		traverse_dyn<false, COUNT, false>(a.tree, ray, FLT_MAX, lds_stack + threadIdx.x, depth, h, wc);
-		a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
+	for (int kind = kOddRays; kind <= kDoubtRays; kind++) {
+		const uint32_t q = ray_queue_index(par, kind, shard);
+		const uint32_t total = a.cnt->n_ray[q];
+		if (kind == kDoubtRays && part == 0 && threadIdx.x == 0 && total)
+			atomicAdd(&a.cnt->retraced, (unsigned long long)total);
+		for (uint32_t i = part * kBlock + threadIdx.x; i < total; i += parts * kBlock) {
+			const uint32_t slot = a.q_ray[(size_t)q * a.shard_cap + i];
+			const float4 r0 = a.ray0[slot], r1 = a.ray1[slot];
+			Ray ray = {mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y)};
+			HitRec h;
+			traverse_dyn<false, COUNT, false>(a.tree, ray, FLT_MAX, lds_stack + threadIdx.x, depth, h, wc);
+			a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
+		}
 	}
 	if (COUNT)
 		count_flush(a.cnt, wc);
@@ -1062,10 +1111,24 @@ void launch_intersect(hipStream_t s, const RenderArgs &a, int par, int depth, bo
 		hipLaunchKernelGGL(k_intersect_leafwise<true>, dim3(leafwise_blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);
 	else if (a.leafwise)
 		hipLaunchKernelGGL(k_intersect_leafwise<false>, dim3(leafwise_blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);
-	else if (count)
-		hipLaunchKernelGGL(k_intersect<true>, dim3(blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);
-	else
-		hipLaunchKernelGGL(k_intersect<false>, dim3(blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);
+	else if (a.wide_cap) {
+		// one LDS column per lane serves the exact traversal's stack (camera rays) and the certified walk
+		const size_t lds = stack_bytes(std::max(depth, (int)a.wide_cap));
+		static const bool split = getenv("RTA_SPLIT_INTERSECT") != nullptr;      // measurement: the two parts as two launches
+		if (count)
+			hipLaunchKernelGGL((k_intersect<true, true>), dim3(blocks), dim3(kBlock), lds, s, a, par, depth);
+		else if (split) {
+			hipLaunchKernelGGL((k_intersect<false, true, 1>), dim3(blocks), dim3(kBlock), lds, s, a, par, depth);
+			hipLaunchKernelGGL((k_intersect<false, true, 2>), dim3(blocks), dim3(kBlock), lds, s, a, par, depth);
+		} else
+			hipLaunchKernelGGL((k_intersect<false, true>), dim3(blocks), dim3(kBlock), lds, s, a, par, depth);
+	} else if (count)
+		hipLaunchKernelGGL((k_intersect<true, false>), dim3(blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);
+	else if (getenv("RTA_SPLIT_INTERSECT")) {
+		hipLaunchKernelGGL((k_intersect<false, false, 1>), dim3(blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);
+		hipLaunchKernelGGL((k_intersect<false, false, 2>), dim3(blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);
+	} else
+		hipLaunchKernelGGL((k_intersect<false, false>), dim3(blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);
 	// on a tame tree odd rays are rare: one workgroup per sub-queue is plenty
 	const unsigned odd_blocks = a.tree.tame ? kShards : kShards * (a.grid_cap / kBlock);
 	if (count)

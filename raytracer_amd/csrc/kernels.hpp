@@ -13,7 +13,7 @@ namespace rta {
 // 16-byte quads per primitive record: three hold it, the fourth keeps a record inside one 64-byte line
 constexpr int kPrimQuads = 4;
 constexpr uint32_t kShards = 64;      // sub-queues per ray queue
-constexpr uint32_t kRayKinds = 3;     // camera rays, bounce rays, rays needing the division-based box test
+constexpr uint32_t kRayKinds = 4;     // camera rays, bounce rays, rays needing the division-based box test, rays to trace again
 
 // Device-resident progress and statistics of one slot group (see RenderArgs).
 struct Counters {
@@ -26,6 +26,7 @@ struct Counters {
 	uint32_t head[2 * kShards];                  // bounce-ray entries already drawn by traversal waves, [step parity][shard]
 	unsigned long long inner, tri, sph;     // RTA_RENDER_COUNT_WORK only
 	unsigned long long early;               // closest-hit queries answered where the ray was generated
+	unsigned long long retraced;            // closest-hit queries that the certified walk left to the exact traversal
 };
 
 struct TreeRef {
@@ -40,6 +41,7 @@ struct TreeRef {
 	const float4 *leaf_boxes;    // 2 quads per primitive: the box of its leaf in the reference's tree
 	float wide_center[3];        // a ray may take the wide tree when |origin - wide_center|^2 <= wide_reach2
 	float wide_reach2;           //   and |direction|^2 <= kWideMaxDir^2
+	uint32_t wide_index_mask;    // 2^bits - 1: the bits of a child reference, stack or list entry that number the node or primitive
 };
 
 constexpr uint32_t kWideLeaf = 0x80000000u;     // child reference of a wide node: kWideLeaf | primitive,
@@ -68,11 +70,16 @@ struct RenderArgs {
 	uint4 *meta;                   // pixel, current block, end of the block run, index in the padded pixel list
 	uint32_t n_slots;
 	uint32_t *q_ray;               // closest-hit queues, [step parity][kind][shard][shard_cap] slot numbers
+	// The bounce-ray queues also carry the rays, [step parity][shard][shard_cap] x 2 quads (origin, direction.x)
+	// (direction.yz, slot, -): traversal waves take their rays in queue order from consecutive
+	// lines instead of gathering them from the slot arrays, whose latency a refilling wave would sit out
+	float4 *q_bounce;
 	uint32_t shard_cap;            // entries per sub-queue, a multiple of the workgroup size
 	uint32_t grid_cap;             // entries per sub-queue that a traversal launch's grid covers: a multiple of the workgroup
 	                               // size, <= shard_cap, and at least the number of slots that can still queue a ray
 	uint32_t rays_per_lane, refill_at;     // bounce-ray traversal: see traverse_pulling
 	uint32_t leafwise;             // the tree has long leaves: traverse_leafwise, one ray per lane (rays_per_lane = 1)
+	uint32_t wide_cap;             // > 0: bounce rays take the certified walk over the wide tree, with this many LDS entries per lane
 	// occlusion queue, 3 per entry: (origin, limit) (direction, slot) (radiance, -)
 	float4 *shadow;
 	Counters *cnt;                 // this group's

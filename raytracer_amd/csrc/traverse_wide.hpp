@@ -123,6 +123,7 @@ struct WideTraversal {
 		const uint32_t ny01 = sy ? q2.x : q0.z, ny23 = sy ? q2.y : q0.w, fy01 = sy ? q0.z : q2.x, fy23 = sy ? q0.w : q2.y;
 		const uint32_t nz01 = sz ? q2.z : q1.x, nz23 = sz ? q2.w : q1.y, fz01 = sz ? q1.x : q2.z, fz23 = sz ? q1.y : q2.w;
 		const float reach = best * (1.f + 0x1p-20f);      // +inf while nothing is hit
+		const uint32_t dmask = 0x7fffffffu & ~tree.wide_index_mask;
 		uint32_t key[4];
 #define RTA_WIDE_HALF(word, part) ((float)__builtin_bit_cast(h2, word).part)
 #define RTA_WIDE_CHILD(s, pair, part, ref)                                                        \
@@ -135,7 +136,7 @@ struct WideTraversal {
 		const float xz = __builtin_fmaf(RTA_WIDE_HALF(fz##pair, part), rcp.z, off.z);             \
 		const float t0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(ex, ey), ez), 0.f);      \
 		const float t1 = __builtin_fminf(__builtin_fminf(__builtin_fminf(xx, xy), xz), reach);    \
-		key[s] = t0 <= t1 ? (ref | entry_distance(t0)) : 0xffffffffu;                             \
+		key[s] = t0 <= t1 ? (ref | (__float_as_uint(t0) & dmask)) : 0xffffffffu;                  \
 	}
 		RTA_WIDE_CHILD(0, 01, x, refs.x)
 		RTA_WIDE_CHILD(1, 01, y, refs.y)
@@ -159,7 +160,7 @@ struct WideTraversal {
 		// The nearest node is visited next; the other nodes go on the stack and the triangles
 		// on the list, the farthest first.  Nodes come first in the order, so key[i] being a
 		// node means that key[0] is one too.
-		node = (int32_t)key[0] >= 0 ? (key[0] & kEntryIndex) : kWideNone;
+		node = (int32_t)key[0] >= 0 ? (key[0] & tree.wide_index_mask) : kWideNone;
 #pragma unroll
 		for (int i = 3; i >= 1; i--)
 			if ((int32_t)key[i] >= 0) {
@@ -174,34 +175,24 @@ struct WideTraversal {
 			}
 	}
 
-	// Stack and list entries are the keys of visit(): bits 23-30 hold the distance at
-	// which the ray enters the box, rounded DOWN to 5 exponent bits (2^-16 .. 2^15)
-	// and 3 significand bits; an entry is dropped when it comes up and even that lower
-	// bound lies beyond the nearest hit so far.
-	static constexpr uint32_t kEntryIndex = 0x007fffffu;
-	// t >= 0
-	RTA_DEV static uint32_t entry_distance(float t)
-	{
-		const uint32_t top = __float_as_uint(t) >> 20;     // 8 exponent bits, 3 significand bits
-		const uint32_t q = top < 888u ? 0u : (top - 888u < 255u ? top - 888u : 255u);      // 888 = 111 << 3: 2^-16
-		return q << 23;
-	}
-	RTA_DEV static float entry_lower_bound(uint32_t entry)
-	{
-		const uint32_t q = (entry >> 23) & 0xffu;
-		return q ? __uint_as_float((q + 888u) << 20) : 0.f;
-	}
+	// Stack and list entries are the keys of visit(): below the triangle bit the leading bits
+	// of the distance at which the ray enters the box (a non-negative float with its low bits
+	// cleared: a lower bound), then as many bits of node or primitive number as the scene
+	// needs (TreeRef::wide_index_mask).  An entry is dropped when it comes up and even that
+	// lower bound lies beyond the nearest hit so far.
+	RTA_DEV static float entry_lower_bound(uint32_t entry, uint32_t dmask) { return __uint_as_float(entry & dmask); }
 
 	// the next node from the stack whose box the ray may still have to enter (at most two tries per trip)
-	RTA_DEV void take_node(uint32_t *stack)
+	RTA_DEV void take_node(const DeviceTree &tree, uint32_t *stack)
 	{
 		const float reach = best * (1.f + 0x1p-20f);
+		const uint32_t dmask = 0x7fffffffu & ~tree.wide_index_mask;
 #pragma unroll
 		for (int k = 0; k < 2; k++)
 			if (node == kWideNone && sp > 0) {
 				const uint32_t e = stack[(--sp) * STRIDE];
-				if (entry_lower_bound(e) <= reach)
-					node = e & kEntryIndex;
+				if (entry_lower_bound(e, dmask) <= reach)
+					node = e & tree.wide_index_mask;
 			}
 	}
 
@@ -209,18 +200,19 @@ struct WideTraversal {
 	RTA_DEV void test_listed(const DeviceTree &tree, uint32_t *stack, const int cap, WorkCount &work)
 	{
 		const float reach = best * (1.f + 0x1p-20f);
+		const uint32_t dmask = 0x7fffffffu & ~tree.wide_index_mask;
 		uint32_t e = stack[lp * STRIDE];
 		lp++;
-		if (entry_lower_bound(e) > reach) {
+		if (entry_lower_bound(e, dmask) > reach) {
 			if (lp >= cap)
 				return;
 			e = stack[lp * STRIDE];
 			lp++;
-			if (entry_lower_bound(e) > reach)
+			if (entry_lower_bound(e, dmask) > reach)
 				return;
 		}
 		if (COUNT) work.tri++;
-		const uint32_t i = e & kEntryIndex;
+		const uint32_t i = e & tree.wide_index_mask;
 		const float4 *rec = tree.prims + kPrimQuads * (size_t)i;
 		const float4 p0 = rec[0], p1 = rec[1], p2 = rec[2];
 		float tu = 0, tv = 0;
@@ -258,15 +250,16 @@ struct WideTraversal {
 //   tag = load(i, ray)                       fetches ray number i
 //   store(finished, tag, hit, doubt)         called by ALL lanes of the wave together; `finished` lanes
 //                                            hand in their ray's result, or `doubt`: trace it exactly
-// `quorum`: lanes with a listed triangle that make the wave run the triangle test.
+// `quorum`: lanes with a listed triangle that make the wave run the triangle test; `waiting_quorum`: lanes
+// with nothing else to do that make it.
 // per lane; lane 0's trips and runs are the wave's
 struct WideCensus {
 	uint32_t trips, visit_runs, visit_lanes, test_runs, test_lanes;
 };
 
 template <bool COUNT, class Grab, class Load, class Store>
-RTA_DEV void traverse_wide_pulling(const DeviceTree &tree, const uint32_t refill_at, const uint32_t quorum, uint32_t *stack,
-                                   const int cap, WorkCount &work, WideCensus &census, Grab grab, Load load, Store store)
+RTA_DEV void traverse_wide_pulling(const DeviceTree &tree, const uint32_t refill_at, const uint32_t quorum,
+                                   const uint32_t waiting_quorum, uint32_t *stack, const int cap, WorkCount &work, WideCensus &census, Grab grab, Load load, Store store)
 {
 	WideTraversal<COUNT> tr;
 	tr.rest(cap);
@@ -283,8 +276,7 @@ RTA_DEV void traverse_wide_pulling(const DeviceTree &tree, const uint32_t refill
 			if (finished)
 				loaded = false;
 			uint32_t first = 0;
-			const uint32_t got = grab(n_idle, first);
-			dry = got < n_idle;
+			const uint32_t got = grab(n_idle, first, dry);
 			const uint32_t rank =
 			    __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
 			if (!tr.busy(cap) && rank < got) {
@@ -308,8 +300,10 @@ RTA_DEV void traverse_wide_pulling(const DeviceTree &tree, const uint32_t refill
 		const bool listed = tr.has_list(cap);
 		const uint32_t n_visit = (uint32_t)__popcll(__ballot(can_visit));
 		const uint32_t n_listed = (uint32_t)__popcll(__ballot(listed));
+		// lanes that can do nothing but test a triangle
+		const uint32_t n_waiting = (uint32_t)__popcll(__ballot(listed && !can_visit));
 		if (COUNT) census.trips++;
-		if (n_listed >= quorum || n_visit == 0 || __ballot(tr.has_node() && !tr.has_room())) {
+		if (n_listed >= quorum || n_waiting >= waiting_quorum || n_visit == 0 || __ballot(tr.has_node() && !tr.has_room())) {
 			if (COUNT) census.test_runs++, census.test_lanes += listed;
 			if (listed)
 				tr.test_listed(tree, stack, cap, work);
@@ -317,7 +311,7 @@ RTA_DEV void traverse_wide_pulling(const DeviceTree &tree, const uint32_t refill
 		if (n_visit) {
 			if (COUNT) census.visit_runs++, census.visit_lanes += can_visit;
 			if (can_visit) {
-				tr.take_node(stack);
+				tr.take_node(tree, stack);
 				if (tr.node != kWideNone)
 					tr.visit(tree, stack, work);
 			}

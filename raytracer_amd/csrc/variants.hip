@@ -310,18 +310,38 @@ __global__ __launch_bounds__(kBlock) void k_variant_threshold(const DeviceTree t
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_wide_batch(
     const DeviceTree tree, const float *rays, uint64_t n, rta_hit *hits, const int cap, const uint32_t rays_per_lane,
-    const uint32_t refill_at, const uint32_t quorum, unsigned long long *census)
+    const uint32_t refill_at, const uint32_t quorum, const uint32_t waiting_quorum, unsigned long long *census,
+    uint32_t *heads, const uint32_t chunk)
 {
 	extern __shared__ uint32_t lds_stack[];
 	const uint64_t per_wave = 64 * (uint64_t)rays_per_lane;
 	const uint64_t begin = ((uint64_t)blockIdx.x * (kBlock / 64) + threadIdx.x / 64) * per_wave;
 	WorkCount wc = {0, 0, 0};
 	WideCensus cs = {0, 0, 0, 0, 0};
+	if (heads) {
+		// measurement: as the renderer hands out rays, 64 lists with a shared counter each
+		const uint32_t shard = blockIdx.x % 64;
+		const uint64_t lo = n * shard / 64, hi = n * (shard + 1) / 64;
+		const float *mine = rays + lo * 6;
+		rta_hit *out = hits + lo;
+		traverse_wide_pulling<COUNT>(
+		    tree, refill_at, quorum, waiting_quorum, lds_stack + threadIdx.x, cap, wc, cs,
+		    SharedList{(uint32_t)(hi - lo), heads + shard, chunk},
+		    [&](uint32_t i, Ray &ray) {
+			    const float *r = mine + (size_t)i * 6;
+			    ray = Ray{mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5])};
+			    return i;
+		    },
+		    [&](bool finished, uint32_t i, const HitRec &h, bool doubt) {
+			    if (finished)
+				    out[i] = doubt ? rta_hit{-2, 0.f, 0.f, 0.f} : rta_hit{h.prim, h.t, h.u, h.v};
+		    });
+	} else
 	if (begin < n) {
 		const float *mine = rays + begin * 6;
 		rta_hit *out = hits + begin;
 		traverse_wide_pulling<COUNT>(
-		    tree, refill_at, quorum, lds_stack + threadIdx.x, cap, wc, cs,
+		    tree, refill_at, quorum, waiting_quorum, lds_stack + threadIdx.x, cap, wc, cs,
 		    OwnChunk{(uint32_t)(n - begin < per_wave ? n - begin : per_wave), 0u},
 		    [&](uint32_t i, Ray &ray) {
 			    const float *r = mine + (size_t)i * 6;
@@ -385,16 +405,23 @@ static int env_int(const char *name, int fallback)
 void launch_wide_batch(hipStream_t s, const TreeRef &tree, const float *rays, uint64_t n, rta_hit *hits, int depth)
 {
 	const int cap = env_int("RTA_WIDE_CAP", 20), rpl = env_int("RTA_WIDE_RPL", 8), refill = env_int("RTA_WIDE_REFILL", 24),
-	          quorum = env_int("RTA_WIDE_QUORUM", 24), count = env_int("RTA_WIDE_COUNT", 0);
+	          quorum = env_int("RTA_WIDE_QUORUM", 24), wq = env_int("RTA_WIDE_WAITING", 64), count = env_int("RTA_WIDE_COUNT", 0);
 	const uint64_t per_block = (uint64_t)kBlock * (uint64_t)rpl;
 	const unsigned blocks = (unsigned)((n + per_block - 1) / per_block);
 	const size_t lds = (size_t)cap * kBlock * sizeof(uint32_t);
+	static uint32_t *heads = nullptr;
+	if (env_int("RTA_WIDE_SHARED", 0)) {
+		if (!heads)
+			(void)hipMalloc((void **)&heads, 64 * sizeof(uint32_t));
+		(void)hipMemsetAsync(heads, 0, 64 * sizeof(uint32_t), s);
+	}
+	uint32_t *use_heads = env_int("RTA_WIDE_SHARED", 0) ? heads : nullptr;
 	if (count) {
 		unsigned long long *census = nullptr, host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 		(void)hipMalloc((void **)&census, sizeof host);
 		(void)hipMemsetAsync(census, 0, sizeof host, s);
 		hipLaunchKernelGGL(k_wide_batch<true>, dim3(blocks), dim3(kBlock), lds, s, tree, rays, n, hits, cap, (uint32_t)rpl,
-		                   (uint32_t)refill, (uint32_t)quorum, census);
+		                   (uint32_t)refill, (uint32_t)quorum, (uint32_t)wq, census, use_heads, (uint32_t)env_int("RTA_WIDE_CHUNK", 256));
 		(void)hipMemcpyAsync(host, census, sizeof host, hipMemcpyDeviceToHost, s);
 		(void)hipStreamSynchronize(s);
 		(void)hipFree(census);
@@ -405,7 +432,7 @@ void launch_wide_batch(hipStream_t s, const TreeRef &tree, const float *rays, ui
 		        (double)host[6] * 64 / (double)n, (double)host[7] / (double)(host[6] ? host[6] : 1));
 	} else {
 		hipLaunchKernelGGL(k_wide_batch<false>, dim3(blocks), dim3(kBlock), lds, s, tree, rays, n, hits, cap, (uint32_t)rpl,
-		                   (uint32_t)refill, (uint32_t)quorum, (unsigned long long *)nullptr);
+		                   (uint32_t)refill, (uint32_t)quorum, (uint32_t)wq, (unsigned long long *)nullptr, use_heads, (uint32_t)env_int("RTA_WIDE_CHUNK", 256));
 	}
 	hipLaunchKernelGGL(k_wide_redo, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock),
 	                   (size_t)depth * kBlock * sizeof(uint32_t), s, tree, rays, n, hits, depth);

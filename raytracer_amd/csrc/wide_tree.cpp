@@ -188,12 +188,6 @@ inline float below(double x)
 	return (double)f <= x ? f : std::nextafterf(f, -INFINITY);
 }
 
-inline float above(double x)
-{
-	float f = (float)x;
-	return (double)f >= x ? f : std::nextafterf(f, INFINITY);
-}
-
 }  // namespace
 
 WideTree build_wide_tree(const rta_scene_desc &d, bool tame)
@@ -360,6 +354,9 @@ WideTree build_wide_tree(const rta_scene_desc &d, bool tame)
 		return refuse("coordinates beyond the range of the wide tree's binary16 planes");
 	w.depth = emit.depth;
 	w.n_nodes = (uint32_t)(w.nodes.size() / 4);
+	w.index_mask = 1;
+	while (w.index_mask < (uint32_t)d.n_prims || w.index_mask < w.n_nodes)
+		w.index_mask = w.index_mask * 2 + 1;
 	w.mean_pad_over_extent = emit.widened_n ? emit.widened_sum / (double)emit.widened_n : 0;
 	w.enabled = true;
 	return w;

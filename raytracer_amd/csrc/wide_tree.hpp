@@ -30,6 +30,7 @@ struct WideTree {
 	float reach = 0;                  //   and |direction| <= kWideMaxDir
 	int depth = 0;                    // levels of wide nodes
 	uint32_t n_nodes = 0;
+	uint32_t index_mask = 0;          // 2^bits - 1 >= every node and primitive number
 	double mean_pad_over_extent = 0;  // diagnostic: padding relative to the padded child boxes' mean extent
 };
 

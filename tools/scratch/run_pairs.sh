@@ -1,0 +1,6 @@
+set -e
+cd $GRAFT_REPO_ROOT
+export RTA_WIDE_RPL=8 RTA_WIDE_REFILL=16 RTA_WIDE_WAITING=16
+TILE=8 RTA_WIDE_COUNT=1 REPS=1 VARIANTS=20 timeout -k 10 120 python -u tools/probe_pairs.py 2>&1 | grep -v amdgpu
+TILE=8 REPS=5 VARIANTS=0,20 timeout -k 10 120 python -u tools/probe_pairs.py 2>&1 | grep -v amdgpu
+TILE=1 REPS=5 VARIANTS=0,20 timeout -k 10 120 python -u tools/probe_pairs.py 2>&1 | grep -v amdgpu

@@ -247,6 +247,19 @@ def test_bulk_rays_bit_exact(gpu, name):
             dist = (rng.random(chunk, dtype=np.float32) * np.float32(np.linalg.norm(hi - lo))).astype(np.float32)
             got = gpu.trace_closest(rr)
             occ = gpu.trace_occluded(rr, dist)
+            if name == "dragon.txt":
+                # the certified walk over the wide tree (and the exact traversal for the rays it hands on)
+                import torch
+                rt = torch.from_numpy(rr).cuda()
+                ht = torch.zeros((chunk, 4), dtype=torch.float32, device=rt.device)
+                torch.cuda.synchronize()
+                gpu.trace_variant_device(20, rt.data_ptr(), chunk, ht.data_ptr())
+                walked = ht.cpu().numpy()
+                assert np.array_equal(walked[:, 0].view(np.int32), got["prim"]), f"walk, part {part}"
+                assert np.array_equal(walked[:, 1].view(np.uint32), got["t"].view(np.uint32)), f"walk, part {part}"
+                hit_w = got["prim"] >= 0
+                assert np.array_equal(walked[hit_w, 2:4].view(np.uint32),
+                                      np.stack([got["u"], got["v"]], axis=1)[hit_w].view(np.uint32)), f"walk, part {part}"
             pieces = np.array_split(np.arange(chunk), 16)
             want = list(pool.map(lambda ix: osc.trace_closest(rr[ix]), pieces))
             wocc = np.concatenate(list(pool.map(lambda ix: osc.trace_occluded(rr[ix], dist[ix]), pieces)))

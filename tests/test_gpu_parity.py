@@ -432,6 +432,7 @@ def test_design_variants_return_the_same_bits(gpu):
     rt = torch.from_numpy(np.ascontiguousarray(rr)).to(dev)
     for variant in (0, 1, 2, 3, 4, 5, 101, 124):
         ht = torch.zeros((rr.shape[0], 4), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
         gpu.trace_variant_device(variant, rt.data_ptr(), rr.shape[0], ht.data_ptr())
         got = ht.cpu().numpy()
         assert np.array_equal(got[:, 0].view(np.int32), want["prim"]), variant

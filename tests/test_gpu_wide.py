@@ -1,0 +1,161 @@
+"""The certified walk over the wide tree (csrc/traverse_wide.hpp) against the
+traversal that replays the reference's visit order (src/main.cpp:332-422), and
+through it against the CPU checker: same primitive, t, u, v bits for every ray,
+whether the walk proves its answer or hands the ray on."""
+import numpy as np
+import pytest
+
+import orc
+import rays as raygen
+import raytracer_amd as rta
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def walk(gpu, rr):
+    """rta_debug_trace_variant 20: the certified walk, then the exact traversal for the rays left in doubt."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rt = torch.from_numpy(np.ascontiguousarray(rr, np.float32)).to(dev)
+    ht = torch.zeros((rr.shape[0], 4), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()      # the library works on its own streams: torch's fill and copy must be through
+    gpu.trace_variant_device(20, rt.data_ptr(), rr.shape[0], ht.data_ptr())
+    return ht.cpu().numpy()
+
+
+def same_hits(got, want):
+    hit = want["prim"] >= 0
+    ok = got[:, 0].view(np.int32) == want["prim"]
+    ok &= got[:, 1].view(np.uint32) == bits(want["t"])
+    ok &= ~hit | ((got[:, 2].view(np.uint32) == bits(want["u"])) & (got[:, 3].view(np.uint32) == bits(want["v"])))
+    return ok
+
+
+def _grid_mesh(n, z_of):
+    """2 n^2 triangles over the unit square, heights from z_of(x, y); vertices on a binary grid, so rays
+    aimed at them meet shared edges and corners exactly."""
+    tris = []
+    h = 1.0 / n
+    for i in range(n):
+        for j in range(n):
+            p = [(i * h, j * h), ((i + 1) * h, j * h), ((i + 1) * h, (j + 1) * h), (i * h, (j + 1) * h)]
+            q = [(x, y, z_of(x, y)) for x, y in p]
+            tris.append(q[0] + q[1] + q[2])
+            tris.append(q[0] + q[2] + q[3])
+    return np.asarray(tris, np.float32)
+
+
+def _mesh_scene(tris):
+    body = " ".join("%r" % float(x) for x in tris.reshape(-1))
+    return ("render {\n\tcamera [0.5 0.5 3]\n\tlook_at [0.5 0.5 0]\n\tup [0 1 0]\n\twidth 48\n\theight 48\n\tsamples 8\n"
+            "\tsky_box_color [.5 .6 1]\n}\n\nmaterial {\n\tcolor [0.8 0.7 0.6]\n\troughness 1\n}\n\n"
+            "triangle_mesh {\n\tvertices [ %s ]\n}\n" % body)
+
+
+def test_walk_equals_the_order_replaying_traversal_on_the_dragon(gpu):
+    osc = orc.Scene.load(f"{orc.SCENES}/dragon.txt").build_bvh()
+    psc = rta.Scene.load(f"{orc.SCENES}/dragon.txt").build_bvh()
+    gpu.upload(psc)
+    nodes = osc.nodes()
+    lo, hi = nodes["lo"][0], nodes["hi"][0]
+    rng = np.random.default_rng(3)
+    inside = raygen.random_rays(400000, lo, hi, seed=21)
+    first = gpu.trace_closest(inside)
+    hit = first["prim"] >= 0
+    # rays leaving the surface, as bounce rays do
+    bounce = inside[hit].copy()
+    bounce[:, 0:3] += bounce[:, 3:6] * first["t"][hit, None]
+    d = rng.standard_normal(bounce[:, 3:6].shape).astype(np.float32)
+    bounce[:, 3:6] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    # rays aimed at vertices: they meet the triangles around the vertex at (nearly) the same distance
+    geom = psc.arrays()["prim_geom"]
+    verts = geom.reshape(-1, 3)[rng.integers(0, geom.shape[0] * 3, 100000)]
+    o = (lo + (hi - lo) * rng.random((verts.shape[0], 3), dtype=np.float32)).astype(np.float32)
+    d = (verts - o).astype(np.float32)
+    aimed = np.concatenate([o, d / np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)], axis=1)
+    # outside what the walk admits: far origins, long and tiny directions, zero components, NaN
+    far = raygen.random_rays(20000, lo - 30, hi + 30, seed=5)
+    long_dir = inside[:20000].copy()
+    long_dir[:, 3:6] *= 5
+    odd = np.concatenate([raygen.axis_rays(), np.float32([[0, 0, 1, np.nan, 0, 1], [np.nan, 0, 1, 0, 0, 1], [0, 0, 1, 1e-30, 1, 1e-30],
+                                                         [0, 0, 1, 0, 0, 0]])])
+    for label, rr in (("inside", inside), ("bounce", bounce), ("aimed at vertices", aimed), ("far", far), ("long", long_dir), ("odd", odd)):
+        want = gpu.trace_closest(rr)
+        ok = same_hits(walk(gpu, rr), want)
+        assert ok.all(), f"{label}: {(~ok).sum()} rays differ, first {rr[np.nonzero(~ok)[0][0]].tolist()}"
+    # and the exact traversal is the checker's (a sample; tests/test_gpu_parity.py covers it at length)
+    sample = np.concatenate([bounce[:20000], aimed[:20000]])
+    idx, t, u, v = osc.trace_closest(sample)
+    want = dict(prim=idx, t=t, u=u, v=v)
+    assert same_hits(walk(gpu, sample), want).all()
+
+
+@pytest.mark.parametrize("shape", ["corner", "bumpy"])
+def test_ties_and_flat_boxes_are_handed_on(gpu, shape):
+    """A triangulated grid: rays through its vertices and along its edges hit two to six triangles at the same
+    distance, and a flat grid's boxes (the floor and the wall of "corner") have no thickness, so the distance to a leaf's box equals the hit's.  The
+    walk cannot prove such answers; the renders must still agree bit for bit with the checker, and report the
+    rays that were handed on."""
+    z_of = (lambda x, y: 0.0) if shape == "corner" else (lambda x, y: 0.25 * np.sin(7 * x) * np.cos(5 * y))
+    tris = _grid_mesh(24, z_of)
+    if shape == "corner":
+        # a flat floor and a flat wall (the floor's grid stood up on the plane x = 0): paths bounce between them
+        wall = tris.reshape(-1, 3, 3)[:, :, [2, 1, 0]]
+        tris = np.concatenate([tris, wall.reshape(-1, 9)])
+    text = _mesh_scene(tris)
+    osc = orc.Scene.parse(text).build_bvh()
+    psc = rta.Scene.parse(text).build_bvh()
+    gpu.upload(psc)
+    rng = np.random.default_rng(11)
+    # from above and below, through grid vertices, edge midpoints and random points, straight and slanted
+    k = rng.integers(0, 25, (60000, 2))
+    target = np.stack([k[:, 0] / 24, k[:, 1] / 24], axis=1)
+    target[20000:40000, 0] += 1 / 48                      # on an edge
+    target[40000:] = rng.random((20000, 2))
+    tz = np.array([z_of(x, y) for x, y in target], np.float64)
+    o = np.stack([target[:, 0] + rng.choice([0, 0.25, -0.5], 60000), target[:, 1] + rng.choice([0, 0.125], 60000),
+                  rng.choice([1.0, -1.0, 0.5], 60000)], axis=1)
+    d = np.stack([target[:, 0], target[:, 1], tz], axis=1) - o
+    rr = np.concatenate([o, d / np.linalg.norm(d, axis=1, keepdims=True)], axis=1).astype(np.float32)
+    idx, t, u, v = osc.trace_closest(rr)
+    want = dict(prim=idx, t=t, u=u, v=v)
+    got = walk(gpu, rr)
+    ok = same_hits(got, want)
+    assert ok.all(), f"{(~ok).sum()} rays differ, first {rr[np.nonzero(~ok)[0][0]].tolist()}"
+    assert (idx >= 0).sum() > 30000
+    # the same scene rendered: bounce rays start ON the grid
+    want_bgr, want_acc, cn = osc.render(orc.RNG_STREAM, orc.MATH_PM, seed=3, samples_per_stream=4)
+    bgr, acc, st = gpu.render_scene(psc, seed=3, samples_per_stream=4)
+    assert st["rays"] == cn["rays"]
+    assert np.array_equal(bits(acc), bits(want_acc)) and np.array_equal(bgr, want_bgr)
+    if shape == "corner":
+        assert st["retraced_rays"] > 0
+
+
+def test_render_with_and_without_the_wide_tree(gpu):
+    text = orc.scene_variant("dragon.txt", 320, 180, 48)
+    psc = rta.Scene.parse(text).build_bvh()
+    gpu.upload(psc)
+    bgr_a, acc_a, st_a = gpu.render_scene(psc, seed=9, samples_per_stream=8)
+    bgr_b, acc_b, st_b = gpu.render_scene(psc, seed=9, samples_per_stream=8, flags=rta.RENDER_EXACT_ONLY)
+    assert np.array_equal(bits(acc_a), bits(acc_b)) and np.array_equal(bgr_a, bgr_b)
+    assert st_a["rays"] == st_b["rays"] and st_a["early_rays"] == st_b["early_rays"]
+    assert st_b["retraced_rays"] == 0
+    # the walk answers all but a sliver of the bounce rays itself
+    bounce = st_a["rays"] - st_a["samples"]
+    assert bounce > 100000 and st_a["retraced_rays"] < bounce // 1000
+
+
+def test_scenes_without_a_wide_tree_render_as_before(gpu):
+    """Spheres keep a scene on the exact traversal (cornell_box.txt has one); variant 20 says so."""
+    psc = rta.Scene.load(f"{orc.SCENES}/cornell_box.txt").build_bvh()
+    gpu.upload(psc)
+    with pytest.raises(rta.RtaError):
+        walk(gpu, raygen.axis_rays())
+    psc.set_render(64, 36, 4)
+    _, _, st = gpu.render_scene(psc, seed=1, samples_per_stream=2)
+    assert st["retraced_rays"] == 0

@@ -367,6 +367,11 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 	uint32_t sky_pixel = 0xffffffffu, sky_pu = 0, sky_pv = 0;     // the pixel sky_u1 belongs to
 	uint32_t repeat = 1;          // samples that the finished sample stands for
 	float sky_u1 = 2.f;
+	// With a sky map, a sample that does need a ray keeps its random numbers and the ray is
+	// made after the loop: per trip only a few lanes get that far, and the ray's logarithm,
+	// sine and cosine (binary64 polynomials) would run for them alone trip after trip.
+	CameraDraws held = {0.f, 0.f, 0.f, 0.f};
+	const bool ray_later = a.sky_map != nullptr;
 	for (uint32_t trip = 0;; trip++) {
 		if (ended) {
 			// the finished sample joins its block sum (src/main.cpp:689)
@@ -471,6 +476,9 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 				answered = true;
 			} else if (const CameraDraws draws = camera_draws(a, rng); trip < a.fast_trips && draws.u1 >= sky_u1) {
 				answered = true;      // too close to the pixel's centre to reach any leaf's box
+			} else if (ray_later) {
+				held = draws;
+				have_ray = true;
 			} else {
 				next_ray = camera_ray(a, sky_pu, sky_pv, draws);
 				have_ray = true;
@@ -488,6 +496,8 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 		}
 	}
 
+	if (ray_later && need_ray)
+		next_ray = camera_ray(a, sky_pu, sky_pv, held);
 	if (need_ray) {
 		a.acc[slot] = A;
 		a.rng[slot] = rng;

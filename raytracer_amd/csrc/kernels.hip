@@ -95,28 +95,42 @@ RTA_DEV void count_flush(Counters *cnt, const WorkCount &wc)
 
 // The closest-hit ray queues: [step parity][kind][shard][capacity] slot numbers,
 // lengths in Counters::n_ray in the same order.
-RTA_DEV uint32_t ray_queue_index(int par, int kind, uint32_t shard) { return ((uint32_t)par * kRayKinds + (uint32_t)kind) * kShards + shard; }
+RTA_DEV uint32_t ray_queue_index(int par, int kind, uint32_t shard) { return ((uint32_t)par * kShards + shard) * kRayKinds + (uint32_t)kind; }
 
-// Queues `slot` (if pred) under `kind`, or under kOddRays when the ray needs the
-// division-based box test.  Must be reached by every lane of the wave.
-RTA_DEV void ray_queue_push(const RenderArgs &a, int par, int kind, bool pred, uint32_t slot, const Ray &ray)
+// A wave's camera rays (lanes with `camera`) and bounce rays (lanes with `bounce`; no lane has
+// both) join their queues with ONE atomic on the shard's 64-bit pair of counters: an atomic that
+// returns a value is a round trip to the memory side that the wave sits out.  Must be reached by
+// every lane of the wave.
+RTA_DEV void ray_queues_push(const RenderArgs &a, int par, bool camera, bool bounce, uint32_t slot, const Ray &ray)
 {
 	const bool tame = a.tree.tame != 0 && ray_is_tame(ray);
 	const uint32_t shard = blockIdx.x % kShards;
-	const uint32_t q = ray_queue_index(par, kind, shard);
-	const uint32_t at = queue_push(pred && tame, &a.cnt->n_ray[q]);
-	if (pred && tame) {
-		a.q_ray[(size_t)q * a.shard_cap + at] = slot;
-		if (kind == kBounceRays) {
+	const unsigned long long cam = __ballot(camera && tame), bnc = __ballot(bounce && tame);
+	if (cam | bnc) {
+		const uint32_t qc = ray_queue_index(par, kCameraRays, shard), qb = ray_queue_index(par, kBounceRays, shard);
+		unsigned long long base = 0;
+		const int leader = __ffsll((long long)(cam | bnc)) - 1;
+		if ((int)(threadIdx.x & 63) == leader)
+			base = atomicAdd(reinterpret_cast<unsigned long long *>(&a.cnt->n_ray[qc]),
+			                 (unsigned long long)__popcll(cam) | ((unsigned long long)__popcll(bnc) << 32));
+		const uint32_t base_c = __shfl((uint32_t)base, leader), base_b = __shfl((uint32_t)(base >> 32), leader);
+		if (camera && tame) {
+			const uint32_t at = base_c + __builtin_amdgcn_mbcnt_hi((uint32_t)(cam >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cam, 0u));
+			a.q_ray[(size_t)qc * a.shard_cap + at] = slot;
+		}
+		if (bounce && tame) {
+			const uint32_t at = base_b + __builtin_amdgcn_mbcnt_hi((uint32_t)(bnc >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bnc, 0u));
+			a.q_ray[(size_t)qb * a.shard_cap + at] = slot;
 			float4 *e = a.q_bounce + 2 * (((size_t)par * kShards + shard) * a.shard_cap + at);
 			e[0] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.d.x);
 			e[1] = make_float4(ray.d.y, ray.d.z, __uint_as_float(slot), 0.f);
 		}
 	}
-	if (__ballot(pred && !tame)) {
+	const bool odd = (camera || bounce) && !tame;
+	if (__ballot(odd)) {
 		const uint32_t qo = ray_queue_index(par, kOddRays, shard);
-		const uint32_t ato = queue_push(pred && !tame, &a.cnt->n_ray[qo]);
-		if (pred && !tame)
+		const uint32_t ato = queue_push(odd, &a.cnt->n_ray[qo]);
+		if (odd)
 			a.q_ray[(size_t)qo * a.shard_cap + ato] = slot;
 	}
 }
@@ -516,9 +530,7 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 
 	// camera rays are coherent (a wave's rays cross one tile), bounce rays are not:
 	// they are queued apart so that a traversal wave holds rays of one kind
-	ray_queue_push(a, par, kCameraRays, need_ray, slot, next_ray);
-	if (__ballot(alive))
-		ray_queue_push(a, par, kBounceRays, alive, slot, next_ray);
+	ray_queues_push(a, par, need_ray, alive, slot, next_ray);
 	if (a.n_lights > 0) {
 		const uint32_t at_sh = queue_push(want_shadow, &a.cnt->n_shadow);
 		if (want_shadow) {
@@ -539,7 +551,7 @@ RTA_DEV void step_housekeeping(const RenderArgs &a, int par)
 {
 	if (threadIdx.x < kRayKinds * kShards) {
 		// (the queue of rays to trace again fills while this launch runs; its rays are counted already)
-		const uint32_t n = threadIdx.x < kDoubtRays * kShards ? a.cnt->n_ray[ray_queue_index(par, 0, 0) + threadIdx.x] : 0;
+		const uint32_t n = threadIdx.x % kRayKinds != (uint32_t)kDoubtRays ? a.cnt->n_ray[ray_queue_index(par, 0, 0) + threadIdx.x] : 0;
 		if (n)
 			atomicAdd(&a.cnt->rays, (unsigned long long)n);
 		a.cnt->n_ray[ray_queue_index(par ^ 1, 0, 0) + threadIdx.x] = 0;

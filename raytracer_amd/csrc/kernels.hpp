@@ -22,7 +22,9 @@ struct Counters {
 	uint32_t live;           // waves that still have or may get work
 	uint32_t pad;
 	unsigned long long rays, shadow_rays;
-	uint32_t n_ray[2 * kRayKinds * kShards];     // closest-hit queue lengths, [step parity][kind][shard]
+	// closest-hit queue lengths, [step parity][shard][kind]: the camera and the bounce counter of a
+	// shard are the halves of one aligned 64-bit word, which k_advance bumps with a single atomic
+	alignas(8) uint32_t n_ray[2 * kRayKinds * kShards];
 	uint32_t head[2 * kShards];                  // bounce-ray entries already drawn by traversal waves, [step parity][shard]
 	unsigned long long inner, tri, sph;     // RTA_RENDER_COUNT_WORK only
 	unsigned long long early;               // closest-hit queries answered where the ray was generated

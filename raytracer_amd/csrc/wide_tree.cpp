@@ -31,6 +31,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace rta {
@@ -125,6 +126,107 @@ struct Builder {
 		return join(l, r);
 	}
 
+	// Surface-area heuristic over ids[begin, end) (16 bins per axis on the centroids): the proof of the
+	// walk does not depend on the tree, so the wide tree need not keep the reference's midpoint splits.
+	int32_t sah(int32_t begin, int32_t end)
+	{
+		if (end - begin == 1)
+			return leaf(ids[begin]);
+		auto centroid = [&](int32_t p, int k) {
+			const float *g = d.prim_geom + (size_t)p * 9;
+			return ((double)g[k] + g[3 + k] + g[6 + k]) * (1.0 / 3.0);
+		};
+		auto bounds_of = [&](int32_t p, double *lo, double *hi) {
+			const float *g = d.prim_geom + (size_t)p * 9;
+			for (int k = 0; k < 3; k++) {
+				lo[k] = std::min(lo[k], (double)std::min(g[k], std::min(g[3 + k], g[6 + k])));
+				hi[k] = std::max(hi[k], (double)std::max(g[k], std::max(g[3 + k], g[6 + k])));
+			}
+		};
+		auto area = [](const double *lo, const double *hi) {
+			const double x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
+			return x * y + y * z + z * x;
+		};
+		double clo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, chi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+		for (int32_t i = begin; i < end; i++)
+			for (int k = 0; k < 3; k++) {
+				const double c = centroid(ids[i], k);
+				clo[k] = std::min(clo[k], c);
+				chi[k] = std::max(chi[k], c);
+			}
+		constexpr int kBins = 16;
+		int best_axis = -1, best_bin = 0;
+		double best_cost = DBL_MAX;
+		for (int axis = 0; axis < 3; axis++) {
+			const double extent = chi[axis] - clo[axis];
+			if (!(extent > 0))
+				continue;
+			int count[kBins] = {};
+			double blo[kBins][3], bhi[kBins][3];
+			for (int b2 = 0; b2 < kBins; b2++)
+				for (int k = 0; k < 3; k++) {
+					blo[b2][k] = DBL_MAX;
+					bhi[b2][k] = -DBL_MAX;
+				}
+			for (int32_t i = begin; i < end; i++) {
+				int b2 = (int)((centroid(ids[i], axis) - clo[axis]) / extent * kBins);
+				b2 = b2 < 0 ? 0 : (b2 >= kBins ? kBins - 1 : b2);
+				count[b2]++;
+				bounds_of(ids[i], blo[b2], bhi[b2]);
+			}
+			// areas of the prefixes and suffixes of the bins
+			double right_area[kBins];
+			int right_count[kBins];
+			double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+			int n = 0;
+			for (int b2 = kBins - 1; b2 > 0; b2--) {
+				n += count[b2];
+				for (int k = 0; k < 3; k++) {
+					lo[k] = std::min(lo[k], blo[b2][k]);
+					hi[k] = std::max(hi[k], bhi[b2][k]);
+				}
+				right_count[b2] = n;
+				right_area[b2] = n ? area(lo, hi) : 0;
+			}
+			for (int k = 0; k < 3; k++) {
+				lo[k] = DBL_MAX;
+				hi[k] = -DBL_MAX;
+			}
+			n = 0;
+			for (int b2 = 0; b2 + 1 < kBins; b2++) {
+				n += count[b2];
+				for (int k = 0; k < 3; k++) {
+					lo[k] = std::min(lo[k], blo[b2][k]);
+					hi[k] = std::max(hi[k], bhi[b2][k]);
+				}
+				if (n == 0 || right_count[b2 + 1] == 0)
+					continue;
+				const double cost = area(lo, hi) * n + right_area[b2 + 1] * right_count[b2 + 1];
+				if (cost < best_cost) {
+					best_cost = cost;
+					best_axis = axis;
+					best_bin = b2;
+				}
+			}
+		}
+		int32_t mid;
+		if (best_axis < 0) {
+			mid = begin + (end - begin) / 2;          // all centroids in one point
+		} else {
+			const double extent = chi[best_axis] - clo[best_axis];
+			auto left = [&](int32_t p) {
+				int b2 = (int)((centroid(p, best_axis) - clo[best_axis]) / extent * kBins);
+				b2 = b2 < 0 ? 0 : (b2 >= kBins ? kBins - 1 : b2);
+				return b2 <= best_bin;
+			};
+			mid = (int32_t)(std::partition(ids.begin() + begin, ids.begin() + end, left) - ids.begin());
+			if (mid == begin || mid == end)
+				mid = begin + (end - begin) / 2;
+		}
+		const int32_t l = sah(begin, mid), r = sah(mid, end);
+		return join(l, r);
+	}
+
 	int32_t from_reference(int32_t node)
 	{
 		const int32_t idx = d.node_index[node], cnt = d.node_count[node];
@@ -209,6 +311,7 @@ WideTree build_wide_tree(const rta_scene_desc &d, bool tame)
 	// every primitive's reference leaf, spheres, and nesting of the reference's boxes: a child's
 	// box must lie inside its parent's (the root's own box is never tested, src/main.cpp:338-385)
 	w.leaf_boxes.assign((size_t)d.n_prims * 2, make_float4(0, 0, 0, 0));
+	std::vector<int32_t> covered;      // the primitives that some leaf holds
 	{
 		std::vector<int32_t> todo = {0};
 		while (!todo.empty()) {
@@ -226,6 +329,7 @@ WideTree build_wide_tree(const rta_scene_desc &d, bool tame)
 							return refuse("non-finite vertex");
 					w.leaf_boxes[(size_t)p * 2] = make_float4(nb[0], nb[1], nb[2], 0);
 					w.leaf_boxes[(size_t)p * 2 + 1] = make_float4(nb[3], nb[4], nb[5], 0);
+					covered.push_back(p);
 				}
 				continue;
 			}
@@ -242,7 +346,16 @@ WideTree build_wide_tree(const rta_scene_desc &d, bool tame)
 
 	Builder bu(d);
 	bu.b.reserve((size_t)d.n_prims * 2);
-	const int32_t root = bu.from_reference(0);
+	// Topology: by surface-area heuristic where the build stays short, else the reference's own.  (Both
+	// put every covered primitive in exactly one leaf; the reference's tree always supplies the leaf
+	// boxes of step 3 of the proof.)
+	int32_t root;
+	if (covered.size() <= kWideSahLimit && !getenv("RTA_WIDE_MIDPOINT")) {
+		bu.ids = covered;
+		root = bu.sah(0, (int32_t)covered.size());
+	} else {
+		root = bu.from_reference(0);
+	}
 	const std::vector<BNode> &b = bu.b;
 
 	// the admitted rays

@@ -38,6 +38,10 @@ struct WideTree {
 // rays do) are admitted; the padding grows with this number
 constexpr float kWideReachRadii = 2.05f;
 
+// primitives up to which the wide tree gets a surface-area-heuristic topology of its own (a host-side build,
+// O(n log n)); beyond, it keeps the reference tree's
+constexpr size_t kWideSahLimit = 2u << 20;
+
 // `tame`: every box coordinate of the reference's tree is ordinary (see ray_is_tame)
 WideTree build_wide_tree(const rta_scene_desc &d, bool tame);
 

@@ -131,6 +131,15 @@ TreeRef tree_of(const rta_context *ctx)
 	memcpy(t.wide_center, ctx->wide_center, 12);
 	t.wide_reach2 = ctx->wide_reach2;
 	t.wide_index_mask = ctx->wide_index_mask;
+	t.wide_index_bits = (uint32_t)__builtin_popcount(ctx->wide_index_mask);
+	// with fewer than 11 bits left for the distance, a float's leading bits say too little
+	static const char *relative = getenv("RTA_WIDE_RELATIVE");      // measurement
+	t.wide_relative = relative ? (uint32_t)atoi(relative) : (t.wide_index_bits > 20 && ctx->box_known ? 1u : 0u);
+	// 16 octaves down from the first power of two beyond the longest way through the scene
+	uint32_t top;
+	memcpy(&top, &ctx->wide_span, 4);
+	top = (top & 0x7f800000u) + (1u << 23);
+	t.wide_key_base = top > (16u << 23) ? top - (16u << 23) : 0u;
 	return t;
 }
 
@@ -439,6 +448,7 @@ int rta_upload_scene(rta_context *ctx, const rta_scene_desc *desc)
 		ctx->wide_reach2 = wide.reach * wide.reach * (1.f - 0x1p-20f);
 		ctx->wide_depth = wide.depth;
 		ctx->wide_index_mask = wide.index_mask;
+		ctx->wide_span = wide.span;
 	}
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // the staging vectors die with this call
 	ctx->have_wide = wide.enabled;
@@ -500,7 +510,8 @@ static int tracing_order(rta_context *ctx, const float *d_rays, int64_t n, const
 	return RTA_OK;
 }
 
-int rta_trace_closest(rta_context *ctx, const float *rays, int64_t n, rta_hit *hits, int mem)
+// rta_trace_closest; `walk`: bounce the batch off the certified walk first where the scene has a wide tree
+static int trace_closest(rta_context *ctx, const float *rays, int64_t n, rta_hit *hits, int mem, bool walk)
 {
 	if (!ctx)
 		return RTA_E_INVALID;
@@ -525,12 +536,32 @@ int rta_trace_closest(rta_context *ctx, const float *rays, int64_t n, rta_hit *h
 	const uint32_t *order = nullptr;
 	if (int rc = tracing_order(ctx, d_rays, n, order))
 		return rc;
-	launch_batch_closest(ctx->stream, tree_of(ctx), d_rays, (uint64_t)n, d_hits, ctx->stack_depth, nullptr, order);
+	static const bool exact_only = getenv("RTA_BATCH_EXACT") != nullptr;      // measurement: price the walk
+	static const int cap = getenv("RTA_BATCH_CAP") ? atoi(getenv("RTA_BATCH_CAP")) : kBatchWalkCap;
+	if (walk && ctx->have_wide && n < ((int64_t)1 << 32) && !exact_only) {
+		// the certified walk answers what it can prove; the rest goes through the replaying traversal
+		const size_t list_bytes = ((size_t)n * 4 + 255) & ~(size_t)255;
+		HIP_TRY(ctx, ctx->doubts.reserve(list_bytes + 256));
+		uint32_t *list = ctx->doubts.as<uint32_t>(), *count = (uint32_t *)(ctx->doubts.as<char>() + list_bytes);
+		launch_batch_walk(ctx->stream, tree_of(ctx), d_rays, (uint64_t)n, d_hits, cap, order, list, count);
+		HIP_TRY(ctx, hipGetLastError());
+		uint32_t in_doubt = 0;
+		HIP_TRY(ctx, hipMemcpyAsync(&in_doubt, count, sizeof in_doubt, hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		if (in_doubt)
+			launch_batch_closest(ctx->stream, tree_of(ctx), d_rays, (uint64_t)in_doubt, d_hits, ctx->stack_depth, nullptr, list);
+	} else
+		launch_batch_closest(ctx->stream, tree_of(ctx), d_rays, (uint64_t)n, d_hits, ctx->stack_depth, nullptr, order);
 	HIP_TRY(ctx, hipGetLastError());
 	if (mem == RTA_MEM_HOST)
 		HIP_TRY(ctx, hipMemcpyAsync(hits, d_hits, (size_t)n * sizeof(rta_hit), hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	return RTA_OK;
+}
+
+int rta_trace_closest(rta_context *ctx, const float *rays, int64_t n, rta_hit *hits, int mem)
+{
+	return trace_closest(ctx, rays, n, hits, mem, true);
 }
 
 int rta_debug_trace_variant(rta_context *ctx, int variant, const float *rays, int64_t n, rta_hit *hits, int mem)
@@ -539,6 +570,8 @@ int rta_debug_trace_variant(rta_context *ctx, int variant, const float *rays, in
 		return RTA_E_INVALID;
 	if (variant == 0)
 		return rta_trace_closest(ctx, rays, n, hits, mem);
+	if (variant == 10)      // every ray through the replaying traversal, as scenes without a wide tree are traced
+		return trace_closest(ctx, rays, n, hits, mem, false);
 	if (!ctx->have_scene)
 		return ctx->fail(RTA_E_NO_SCENE, "no scene uploaded");
 	if (variant == 20) {

@@ -59,6 +59,7 @@ struct rta_context {
 	float wide_center[3] = {0, 0, 0}, wide_reach2 = 0;
 	int wide_depth = 0;
 	uint32_t wide_index_mask = 0;
+	float wide_span = 1;
 	rta::DeviceBuffer soa_nodes;      // variant 5 only, made from `pairs` on first use
 	uint32_t n_pairs = 0;
 	bool have_soa = false;
@@ -74,6 +75,7 @@ struct rta_context {
 	rta::DeviceBuffer part_weights, part_order;
 	rta::DeviceBuffer cover, sky_map;         // see k_sky_map
 	rta::DeviceBuffer ray_order;              // see tracing_order
+	rta::DeviceBuffer doubts;                 // rays a batch's certified walk hands on to the exact traversal
 	rta::DeviceBuffer io_a, io_b, io_c;       // staging for host-pointer calls
 	rta::Counters *host_counters = nullptr;   // pinned, kMaxGroups entries
 

@@ -1031,6 +1031,48 @@ __global__ __launch_bounds__(kBlock) void k_batch_closest(const DeviceTree tree,
 		count_flush(cnt, wc);
 }
 
+// The same batch by the certified walk over the wide tree (traverse_wide.hpp).  The rays it cannot
+// answer are listed in `doubts` (ray numbers, *n_doubts of them) for k_batch_closest to trace.
+constexpr uint32_t kBatchWalkRefillAt = 24, kBatchWalkQuorum = 24, kBatchWalkWaiting = 64;
+
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_batch_walk(
+    const DeviceTree tree, const float *rays, uint64_t n, rta_hit *hits, const int cap, const uint32_t rays_per_lane,
+    const uint32_t *order, uint32_t *doubts, uint32_t *n_doubts)
+{
+	extern __shared__ uint32_t lds_stack[];
+	const uint64_t per_wave = 64 * (uint64_t)rays_per_lane;
+	const uint64_t begin = ((uint64_t)blockIdx.x * (kBlock / 64) + threadIdx.x / 64) * per_wave;
+	if (begin >= n)
+		return;
+	const uint32_t *which = order ? order + begin : nullptr;
+	WorkCount wc = {0, 0, 0};
+	WideCensus cs = {0, 0, 0, 0, 0};
+	traverse_wide_pulling<false>(
+	    tree, kBatchWalkRefillAt, kBatchWalkQuorum, kBatchWalkWaiting, lds_stack + threadIdx.x, cap, wc, cs,
+	    OwnChunk{(uint32_t)(n - begin < per_wave ? n - begin : per_wave), 0u},
+	    [&](uint32_t i, Ray &ray) {
+		    const uint32_t number = which ? which[i] : (uint32_t)begin + i;
+		    const float *r = rays + (size_t)number * 6;
+		    ray = Ray{mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5])};
+		    return number;
+	    },
+	    [&](bool finished, uint32_t number, const HitRec &h, bool doubt) {
+		    if (finished && !doubt)
+			    hits[number] = rta_hit{h.prim, h.t, h.u, h.v};
+		    // the wave's rays in doubt join the list with one atomic (rare: most waves have none)
+		    const unsigned long long handed_on = __ballot(finished && doubt);
+		    if (handed_on) {
+			    uint32_t base = 0;
+			    if ((threadIdx.x & 63) == (uint32_t)__builtin_ctzll(handed_on))
+				    base = atomicAdd(n_doubts, (uint32_t)__popcll(handed_on));
+			    base = (uint32_t)__shfl((int)base, __builtin_ctzll(handed_on));
+			    if (finished && doubt)
+				    doubts[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(handed_on >> 32),
+				                                            __builtin_amdgcn_mbcnt_lo((uint32_t)handed_on, 0u))] = number;
+		    }
+	    });
+}
+
 __global__ __launch_bounds__(kBlock) void k_batch_occluded(const DeviceTree tree, const float *rays, const float *tmax,
                                                            uint64_t n, uint8_t *out, const int depth,
                                                            const uint32_t rays_per_lane, const uint32_t *order)
@@ -1194,6 +1236,16 @@ void launch_batch_closest(hipStream_t s, const TreeRef &tree, const float *rays,
 	else
 		hipLaunchKernelGGL(k_batch_closest<false>, dim3(batch_blocks(n)), dim3(kBlock), stack_bytes(depth), s, tree,
 		                   rays, n, hits, depth, cnt, batch_rays_per_lane(n), order);
+}
+
+void launch_batch_walk(hipStream_t s, const TreeRef &tree, const float *rays, uint64_t n, rta_hit *hits, int cap,
+                       const uint32_t *order, uint32_t *doubts, uint32_t *n_doubts)
+{
+	// long runs per wave once the batch fills the GPU several times over
+	const uint32_t rays_per_lane = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, n >> 20));
+	(void)hipMemsetAsync(n_doubts, 0, sizeof(uint32_t), s);
+	hipLaunchKernelGGL(k_batch_walk, dim3(blocks_for((n + rays_per_lane - 1) / rays_per_lane)), dim3(kBlock), stack_bytes(cap), s,
+	                   tree, rays, n, hits, cap, rays_per_lane, order, doubts, n_doubts);
 }
 
 void launch_batch_occluded(hipStream_t s, const TreeRef &tree, const float *rays, const float *tmax, uint64_t n,

@@ -44,11 +44,15 @@ struct TreeRef {
 	float wide_center[3];        // a ray may take the wide tree when |origin - wide_center|^2 <= wide_reach2
 	float wide_reach2;           //   and |direction|^2 <= kWideMaxDir^2
 	uint32_t wide_index_mask;    // 2^bits - 1: the bits of a child reference, stack or list entry that number the node or primitive
+	uint32_t wide_index_bits;    //   and that number of bits
+	uint32_t wide_relative;      // distance bits of the entries count from the ray's entry into the scene's box (big scenes)
+	uint32_t wide_key_base;      //   and are the bits of the float distance above this pattern (WideTraversal::distance_bits)
 };
 
 constexpr uint32_t kWideLeaf = 0x80000000u;     // child reference of a wide node: kWideLeaf | primitive,
 constexpr uint32_t kWideNone = 0xffffffffu;     //   a node number, or kWideNone for an empty child
 constexpr float kWideMaxDir = 2.f;              // longest ray direction the wide tree's padding is computed for
+constexpr int kBatchWalkCap = 20;               // entries of a lane's LDS column (node stack + triangle list) in k_batch_walk
 
 // Everything a wavefront kernel needs, passed by value.  The slot pool is cut
 // into groups that run their wavefront steps on different HIP streams, so that
@@ -146,6 +150,9 @@ void launch_resolve(hipStream_t s, const float *frame, const int32_t *pixels, ui
 // `order`: null, or the n ray numbers in the order in which they are to be traced (n < 2^32)
 void launch_batch_closest(hipStream_t s, const TreeRef &tree, const float *rays, uint64_t n, rta_hit *hits, int depth,
                           Counters *cnt, const uint32_t *order = nullptr);
+// the certified walk over the wide tree; rays left in doubt are listed for launch_batch_closest (order = doubts)
+void launch_batch_walk(hipStream_t s, const TreeRef &tree, const float *rays, uint64_t n, rta_hit *hits, int cap,
+                       const uint32_t *order, uint32_t *doubts, uint32_t *n_doubts);
 void launch_batch_occluded(hipStream_t s, const TreeRef &tree, const float *rays, const float *tmax, uint64_t n,
                            uint8_t *out, int depth, const uint32_t *order = nullptr);
 // sort_rays.hip: the tracing order of a big batch (by origin cell and direction octant)

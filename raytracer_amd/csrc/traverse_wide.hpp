@@ -52,6 +52,7 @@ struct WideTraversal {
 	uint32_t doubt;      // the exact traversal must answer this ray
 	uint32_t node;       // wide node to visit next, or kWideNone
 	int sp, lp;          // stack entries [0, sp), list entries [lp, cap)
+	float t_enter;       // where the ray enters the scene's box (DeviceTree::wide_relative), else 0
 
 	RTA_DEV void rest(const int cap)
 	{
@@ -66,6 +67,7 @@ struct WideTraversal {
 		node = kWideNone;
 		sp = 0;
 		lp = cap;
+		t_enter = 0.f;
 	}
 
 	RTA_DEV void start(const DeviceTree &tree, const Ray &r, const int cap)
@@ -86,6 +88,32 @@ struct WideTraversal {
 		    ray_is_tame(r) && norm2(r.d) <= kWideMaxDir * kWideMaxDir * (1.f - 0x1p-20f) && norm2(from) <= tree.wide_reach2;
 		doubt = !admitted;
 		node = admitted ? 0u : kWideNone;
+		t_enter = 0.f;
+		if (tree.wide_relative) {
+			// (an estimate is enough: distance_bits() is monotonic whatever t_enter is)
+			const float ax = (tree.box_lo[0] - r.o.x) * rcp.x, bx = (tree.box_hi[0] - r.o.x) * rcp.x;
+			const float ay = (tree.box_lo[1] - r.o.y) * rcp.y, by = (tree.box_hi[1] - r.o.y) * rcp.y;
+			const float az = (tree.box_lo[2] - r.o.z) * rcp.z, bz = (tree.box_hi[2] - r.o.z) * rcp.z;
+			t_enter = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)),
+			                          __builtin_fmaxf(__builtin_fminf(az, bz), 0.f));
+			t_enter = admitted && t_enter < FLT_MAX ? t_enter : 0.f;
+		}
+	}
+
+	// The distance part of a key or entry: monotonic in t (t >= 0 or +inf), so that comparing two of them
+	// never contradicts comparing the distances.  Scenes with few primitives leave room for the leading
+	// bits of the float itself.  Scenes with millions leave 7 or 8 bits, less than a float's exponent: there
+	// the distance counts from where the ray enters the scene's box (rays from outside have all their
+	// boxes at much the same distance from the origin), as a short float of 4 exponent bits - 16 octaves
+	// down from the scene's size - and what remains of mantissa.
+	RTA_DEV uint32_t distance_bits(const DeviceTree &tree, float t, uint32_t dmask) const
+	{
+		if (tree.wide_relative) {
+			const uint32_t x = __float_as_uint(__builtin_fmaxf(t - t_enter, 0.f));
+			const uint32_t k = (x > tree.wide_key_base ? x : tree.wide_key_base) - tree.wide_key_base;
+			return ((k < 0x07ffffffu ? k : 0x07ffffffu) << 4) & dmask;
+		}
+		return __float_as_uint(t) & dmask;
 	}
 
 	RTA_DEV bool busy(const int cap) const { return node != kWideNone || sp > 0 || lp < cap; }
@@ -136,7 +164,7 @@ struct WideTraversal {
 		const float xz = __builtin_fmaf(RTA_WIDE_HALF(fz##pair, part), rcp.z, off.z);             \
 		const float t0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(ex, ey), ez), 0.f);      \
 		const float t1 = __builtin_fminf(__builtin_fminf(__builtin_fminf(xx, xy), xz), reach);    \
-		key[s] = t0 <= t1 ? (ref | (__float_as_uint(t0) & dmask)) : 0xffffffffu;                  \
+		key[s] = t0 <= t1 ? (ref | distance_bits(tree, t0, dmask)) : 0xffffffffu;                 \
 	}
 		RTA_WIDE_CHILD(0, 01, x, refs.x)
 		RTA_WIDE_CHILD(1, 01, y, refs.y)
@@ -175,23 +203,22 @@ struct WideTraversal {
 			}
 	}
 
-	// Stack and list entries are the keys of visit(): below the triangle bit the leading bits
-	// of the distance at which the ray enters the box (a non-negative float with its low bits
-	// cleared: a lower bound), then as many bits of node or primitive number as the scene
-	// needs (TreeRef::wide_index_mask).  An entry is dropped when it comes up and even that
-	// lower bound lies beyond the nearest hit so far.
-	RTA_DEV static float entry_lower_bound(uint32_t entry, uint32_t dmask) { return __uint_as_float(entry & dmask); }
+	// Stack and list entries are the keys of visit(): below the triangle bit the distance at
+	// which the ray enters the box as distance_bits() has it (rounded down), then as many bits
+	// of node or primitive number as the scene needs (TreeRef::wide_index_mask).  An entry is
+	// dropped when it comes up and its distance bits exceed those of the nearest hit so far:
+	// distance_bits() is monotonic, so the box is then entered beyond that hit.
 
 	// the next node from the stack whose box the ray may still have to enter (at most two tries per trip)
 	RTA_DEV void take_node(const DeviceTree &tree, uint32_t *stack)
 	{
-		const float reach = best * (1.f + 0x1p-20f);
 		const uint32_t dmask = 0x7fffffffu & ~tree.wide_index_mask;
+		const uint32_t reach = distance_bits(tree, best * (1.f + 0x1p-20f), dmask);
 #pragma unroll
 		for (int k = 0; k < 2; k++)
 			if (node == kWideNone && sp > 0) {
 				const uint32_t e = stack[(--sp) * STRIDE];
-				if (entry_lower_bound(e, dmask) <= reach)
+				if ((e & dmask) <= reach)
 					node = e & tree.wide_index_mask;
 			}
 	}
@@ -199,16 +226,16 @@ struct WideTraversal {
 	// Precondition: has_list(cap)
 	RTA_DEV void test_listed(const DeviceTree &tree, uint32_t *stack, const int cap, WorkCount &work)
 	{
-		const float reach = best * (1.f + 0x1p-20f);
 		const uint32_t dmask = 0x7fffffffu & ~tree.wide_index_mask;
+		const uint32_t reach = distance_bits(tree, best * (1.f + 0x1p-20f), dmask);
 		uint32_t e = stack[lp * STRIDE];
 		lp++;
-		if (entry_lower_bound(e, dmask) > reach) {
+		if ((e & dmask) > reach) {
 			if (lp >= cap)
 				return;
 			e = stack[lp * STRIDE];
 			lp++;
-			if (entry_lower_bound(e, dmask) > reach)
+			if ((e & dmask) > reach)
 				return;
 		}
 		if (COUNT) work.tri++;

@@ -305,7 +305,7 @@ WideTree build_wide_tree(const rta_scene_desc &d, bool tame)
 		return refuse("box coordinates out of the ordinary range");
 	if (d.node_count[0] > 0)
 		return refuse("the root is a leaf");
-	if (d.n_prims >= (1 << 23))
+	if (d.n_prims >= (1 << 26))
 		return refuse("more primitives than a stack entry can number");
 
 	// every primitive's reference leaf, spheres, and nesting of the reference's boxes: a child's
@@ -358,7 +358,7 @@ WideTree build_wide_tree(const rta_scene_desc &d, bool tame)
 	}
 	const std::vector<BNode> &b = bu.b;
 
-	// the admitted rays
+	// the scene's sphere
 	double c[3], r2 = 0, cmax = 0;
 	for (int k = 0; k < 3; k++) {
 		c[k] = .5 * ((double)b[root].lo[k] + b[root].hi[k]);
@@ -369,108 +369,121 @@ WideTree build_wide_tree(const rta_scene_desc &d, bool tame)
 	const double radius = std::sqrt(r2);
 	if (!(radius > 0) || !std::isfinite(radius) || !std::isfinite(cmax))
 		return refuse("degenerate scene box");
-	const double s_max = kWideReachRadii * radius;
 	for (int k = 0; k < 3; k++)
 		w.center[k] = (float)c[k];
-	w.reach = below((kWideReachRadii - 1.001) * radius - 1e-6 * cmax);
-	if (!(w.reach > 0))
-		return refuse("degenerate scene box");
 
-	const double u = 0x1p-24;
-	auto pad = [&](double e) {
-		const double rho = 16.02e4 * u * kWideMaxDir * e * e * (s_max + e) + 2 * u * e;
-		const double dt = 16.02e4 * u * e * e * (s_max + e);
-		const double slab = 8 * u * (s_max + cmax + radius);
-		return 2 * (rho + kWideMaxDir * dt + slab);
-	};
+	// The admitted rays: the padding grows with the distance of the farthest admitted origin, so the
+	// wider reach (rays from outside the scene, a camera's say) is taken only where the boxes stay tight.
+	std::vector<double> candidates = {kWideReachRadiiFar, kWideReachRadii};
+	if (getenv("RTA_WIDE_REACH"))
+		candidates = {atof(getenv("RTA_WIDE_REACH"))};
+	for (size_t trial = 0; trial < candidates.size(); trial++) {
+		const double reach_radii = candidates[trial];
+		const double s_max = reach_radii * radius;
+		w.reach = below((reach_radii - 1.001) * radius - 1e-6 * cmax);
+		w.span = (float)(s_max * 1.001);
+		if (!(w.reach > 0))
+			return refuse("degenerate scene box");
+		w.nodes.clear();
 
-	// collapse, depth first; recursion depth = levels of wide nodes
-	struct Emit {
-		const std::vector<BNode> &b;
-		WideTree &w;
-		decltype(pad) &pad_of;
-		double widened_sum = 0;       // sum over children of (mean widening per side) / (mean extent)
-		uint64_t widened_n = 0;
-		int depth = 0;
-		bool overflow = false;        // a plane beyond binary16's range
+		const double u = 0x1p-24;
+		auto pad = [&](double e) {
+			const double rho = 16.02e4 * u * kWideMaxDir * e * e * (s_max + e) + 2 * u * e;
+			const double dt = 16.02e4 * u * e * e * (s_max + e);
+			const double slab = 8 * u * (s_max + cmax + radius);
+			return 2 * (rho + kWideMaxDir * dt + slab);
+		};
 
-		uint32_t node(int32_t at, int level)
-		{
-			depth = std::max(depth, level);
-			const uint32_t me = (uint32_t)(w.nodes.size() / 4);
-			w.nodes.resize(w.nodes.size() + 4, make_float4(0, 0, 0, 0));
-			int32_t kids[4] = {b[at].left, b[at].right, -1, -1};
-			int n = 2;
-			while (n < 4) {
-				int best = -1;
-				double area = -1;
-				for (int k = 0; k < n; k++)
-					if (b[kids[k]].prim < 0 && surface(b[kids[k]]) > area) {
-						area = surface(b[kids[k]]);
-						best = k;
+		// collapse, depth first; recursion depth = levels of wide nodes
+		struct Emit {
+			const std::vector<BNode> &b;
+			WideTree &w;
+			decltype(pad) &pad_of;
+			double widened_sum = 0;       // sum over children of (mean widening per side) / (mean extent)
+			uint64_t widened_n = 0;
+			int depth = 0;
+			bool overflow = false;        // a plane beyond binary16's range
+
+			uint32_t node(int32_t at, int level)
+			{
+				depth = std::max(depth, level);
+				const uint32_t me = (uint32_t)(w.nodes.size() / 4);
+				w.nodes.resize(w.nodes.size() + 4, make_float4(0, 0, 0, 0));
+				int32_t kids[4] = {b[at].left, b[at].right, -1, -1};
+				int n = 2;
+				while (n < 4) {
+					int best = -1;
+					double area = -1;
+					for (int k = 0; k < n; k++)
+						if (b[kids[k]].prim < 0 && surface(b[kids[k]]) > area) {
+							area = surface(b[kids[k]]);
+							best = k;
+						}
+					if (best < 0)
+						break;
+					const int32_t open = kids[best];
+					for (int k = n; k > best + 1; k--)
+						kids[k] = kids[k - 1];
+					kids[best] = b[open].left;
+					kids[best + 1] = b[open].right;
+					n++;
+				}
+				// planes relative to the centre the kernels subtract from the ray's origin, as binary16
+				// rounded outwards
+				uint16_t plane[6][4];
+				uint32_t ref[4];
+				for (int k = 0; k < 4; k++) {
+					if (k >= n) {
+						for (int a = 0; a < 3; a++) {
+							plane[a][k] = 0x7c00u;          // +inf
+							plane[3 + a][k] = 0xfc00u;      // -inf
+						}
+						ref[k] = kWideNone;
+						continue;
 					}
-				if (best < 0)
-					break;
-				const int32_t open = kids[best];
-				for (int k = n; k > best + 1; k--)
-					kids[k] = kids[k - 1];
-				kids[best] = b[open].left;
-				kids[best + 1] = b[open].right;
-				n++;
-			}
-			// planes relative to the centre the kernels subtract from the ray's origin, as binary16
-			// rounded outwards
-			uint16_t plane[6][4];
-			uint32_t ref[4];
-			for (int k = 0; k < 4; k++) {
-				if (k >= n) {
+					const BNode &kid = b[kids[k]];
+					const double p = pad_of(kid.edge);
+					double extent = 0, widened = 0;
 					for (int a = 0; a < 3; a++) {
-						plane[a][k] = 0x7c00u;          // +inf
-						plane[3 + a][k] = 0xfc00u;      // -inf
+						plane[a][k] = half_below((double)kid.lo[a] - p - (double)w.center[a]);
+						plane[3 + a][k] = half_above((double)kid.hi[a] + p - (double)w.center[a]);
+						const double lo_h = (double)half_of(plane[a][k]), hi_h = (double)half_of(plane[3 + a][k]);
+						if (!std::isfinite(lo_h) || !std::isfinite(hi_h))
+							overflow = true;
+						extent += (hi_h - lo_h) / 3;
+						widened += ((hi_h - lo_h) - ((double)kid.hi[a] - kid.lo[a])) / 6;
 					}
-					ref[k] = kWideNone;
-					continue;
+					if (extent > 0) {
+						widened_sum += widened / extent;
+						widened_n++;
+					}
+					ref[k] = kid.prim >= 0 ? (kWideLeaf | (uint32_t)kid.prim) : node(kids[k], level + 1);
 				}
-				const BNode &kid = b[kids[k]];
-				const double p = pad_of(kid.edge);
-				double extent = 0, widened = 0;
-				for (int a = 0; a < 3; a++) {
-					plane[a][k] = half_below((double)kid.lo[a] - p - (double)w.center[a]);
-					plane[3 + a][k] = half_above((double)kid.hi[a] + p - (double)w.center[a]);
-					const double lo_h = (double)half_of(plane[a][k]), hi_h = (double)half_of(plane[3 + a][k]);
-					if (!std::isfinite(lo_h) || !std::isfinite(hi_h))
-						overflow = true;
-					extent += (hi_h - lo_h) / 3;
-					widened += ((hi_h - lo_h) - ((double)kid.hi[a] - kid.lo[a])) / 6;
+				float4 *rec = &w.nodes[(size_t)me * 4];
+				uint32_t words[12];
+				for (int a = 0; a < 6; a++) {
+					words[a * 2] = (uint32_t)plane[a][0] | ((uint32_t)plane[a][1] << 16);
+					words[a * 2 + 1] = (uint32_t)plane[a][2] | ((uint32_t)plane[a][3] << 16);
 				}
-				if (extent > 0) {
-					widened_sum += widened / extent;
-					widened_n++;
-				}
-				ref[k] = kid.prim >= 0 ? (kWideLeaf | (uint32_t)kid.prim) : node(kids[k], level + 1);
+				for (int q = 0; q < 3; q++)
+					rec[q] = make_float4(as_float(words[q * 4]), as_float(words[q * 4 + 1]), as_float(words[q * 4 + 2]),
+					                     as_float(words[q * 4 + 3]));
+				rec[3] = make_float4(as_float(ref[0]), as_float(ref[1]), as_float(ref[2]), as_float(ref[3]));
+				return me;
 			}
-			float4 *rec = &w.nodes[(size_t)me * 4];
-			uint32_t words[12];
-			for (int a = 0; a < 6; a++) {
-				words[a * 2] = (uint32_t)plane[a][0] | ((uint32_t)plane[a][1] << 16);
-				words[a * 2 + 1] = (uint32_t)plane[a][2] | ((uint32_t)plane[a][3] << 16);
-			}
-			for (int q = 0; q < 3; q++)
-				rec[q] = make_float4(as_float(words[q * 4]), as_float(words[q * 4 + 1]), as_float(words[q * 4 + 2]),
-				                     as_float(words[q * 4 + 3]));
-			rec[3] = make_float4(as_float(ref[0]), as_float(ref[1]), as_float(ref[2]), as_float(ref[3]));
-			return me;
-		}
-	} emit{b, w, pad};
-	emit.node(root, 1);
-	if (emit.overflow)
-		return refuse("coordinates beyond the range of the wide tree's binary16 planes");
-	w.depth = emit.depth;
-	w.n_nodes = (uint32_t)(w.nodes.size() / 4);
-	w.index_mask = 1;
-	while (w.index_mask < (uint32_t)d.n_prims || w.index_mask < w.n_nodes)
-		w.index_mask = w.index_mask * 2 + 1;
-	w.mean_pad_over_extent = emit.widened_n ? emit.widened_sum / (double)emit.widened_n : 0;
+		} emit{b, w, pad};
+		emit.node(root, 1);
+		if (emit.overflow)
+			return refuse("coordinates beyond the range of the wide tree's binary16 planes");
+		w.depth = emit.depth;
+		w.n_nodes = (uint32_t)(w.nodes.size() / 4);
+		w.index_mask = 1;
+		while (w.index_mask < (uint32_t)d.n_prims || w.index_mask < w.n_nodes)
+			w.index_mask = w.index_mask * 2 + 1;
+		w.mean_pad_over_extent = emit.widened_n ? emit.widened_sum / (double)emit.widened_n : 0;
+		if (w.mean_pad_over_extent <= kWideMaxPadding)
+			break;
+	}
 	w.enabled = true;
 	return w;
 }

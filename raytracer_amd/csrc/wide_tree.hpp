@@ -28,6 +28,7 @@ struct WideTree {
 	std::vector<float4> leaf_boxes;
 	float center[3] = {0, 0, 0};      // rays may take the wide tree when |origin - center| <= reach
 	float reach = 0;                  //   and |direction| <= kWideMaxDir
+	float span = 0;                   // >= reach + the radius of the scene's sphere: no admitted ray of unit direction is in the scene beyond
 	int depth = 0;                    // levels of wide nodes
 	uint32_t n_nodes = 0;
 	uint32_t index_mask = 0;          // 2^bits - 1 >= every node and primitive number
@@ -37,6 +38,10 @@ struct WideTree {
 // reach + scene radius, in scene radii: rays that start inside the sphere around the scene's box (bounce
 // rays do) are admitted; the padding grows with this number
 constexpr float kWideReachRadii = 2.05f;
+// the same for rays that start outside (a camera's, a batch's): taken when the padding it costs stays below
+// kWideMaxPadding of the boxes' extents (binary16 rounding of the planes included)
+constexpr float kWideReachRadiiFar = 4.f;
+constexpr double kWideMaxPadding = 0.03;
 
 // primitives up to which the wide tree gets a surface-area-heuristic topology of its own (a host-side build,
 // O(n log n)); beyond, it keeps the reference tree's

@@ -16,15 +16,31 @@ def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
-def walk(gpu, rr):
-    """rta_debug_trace_variant 20: the certified walk, then the exact traversal for the rays left in doubt."""
+def _variant(gpu, variant, rr):
     import torch
     dev = torch.device("cuda", 0)
     rt = torch.from_numpy(np.ascontiguousarray(rr, np.float32)).to(dev)
     ht = torch.zeros((rr.shape[0], 4), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()      # the library works on its own streams: torch's fill and copy must be through
-    gpu.trace_variant_device(20, rt.data_ptr(), rr.shape[0], ht.data_ptr())
+    gpu.trace_variant_device(variant, rt.data_ptr(), rr.shape[0], ht.data_ptr())
     return ht.cpu().numpy()
+
+
+def walk(gpu, rr):
+    """rta_debug_trace_variant 20: the certified walk, then the exact traversal for the rays left in doubt."""
+    return _variant(gpu, 20, rr)
+
+
+def exact(gpu, rr):
+    """rta_debug_trace_variant 10: every ray through the traversal that replays the reference's order."""
+    got = _variant(gpu, 10, rr)
+    return dict(prim=got[:, 0].view(np.int32).copy(), t=got[:, 1].copy(), u=got[:, 2].copy(), v=got[:, 3].copy())
+
+
+def batch(gpu, rr):
+    """rta_trace_closest as callers use it (host buffers): the walk where the scene has a wide tree."""
+    h = gpu.trace_closest(rr)
+    return np.stack([h["prim"].view(np.float32), h["t"], h["u"], h["v"]], axis=1)
 
 
 def same_hits(got, want):
@@ -64,7 +80,7 @@ def test_walk_equals_the_order_replaying_traversal_on_the_dragon(gpu):
     lo, hi = nodes["lo"][0], nodes["hi"][0]
     rng = np.random.default_rng(3)
     inside = raygen.random_rays(400000, lo, hi, seed=21)
-    first = gpu.trace_closest(inside)
+    first = exact(gpu, inside)
     hit = first["prim"] >= 0
     # rays leaving the surface, as bounce rays do
     bounce = inside[hit].copy()
@@ -84,9 +100,10 @@ def test_walk_equals_the_order_replaying_traversal_on_the_dragon(gpu):
     odd = np.concatenate([raygen.axis_rays(), np.float32([[0, 0, 1, np.nan, 0, 1], [np.nan, 0, 1, 0, 0, 1], [0, 0, 1, 1e-30, 1, 1e-30],
                                                          [0, 0, 1, 0, 0, 0]])])
     for label, rr in (("inside", inside), ("bounce", bounce), ("aimed at vertices", aimed), ("far", far), ("long", long_dir), ("odd", odd)):
-        want = gpu.trace_closest(rr)
-        ok = same_hits(walk(gpu, rr), want)
-        assert ok.all(), f"{label}: {(~ok).sum()} rays differ, first {rr[np.nonzero(~ok)[0][0]].tolist()}"
+        want = exact(gpu, rr)
+        for how, got in (("probe", walk(gpu, rr)), ("rta_trace_closest", batch(gpu, rr))):
+            ok = same_hits(got, want)
+            assert ok.all(), f"{label} ({how}): {(~ok).sum()} rays differ, first {rr[np.nonzero(~ok)[0][0]].tolist()}"
     # and the exact traversal is the checker's (a sample; tests/test_gpu_parity.py covers it at length)
     sample = np.concatenate([bounce[:20000], aimed[:20000]])
     idx, t, u, v = osc.trace_closest(sample)
@@ -123,9 +140,9 @@ def test_ties_and_flat_boxes_are_handed_on(gpu, shape):
     rr = np.concatenate([o, d / np.linalg.norm(d, axis=1, keepdims=True)], axis=1).astype(np.float32)
     idx, t, u, v = osc.trace_closest(rr)
     want = dict(prim=idx, t=t, u=u, v=v)
-    got = walk(gpu, rr)
-    ok = same_hits(got, want)
-    assert ok.all(), f"{(~ok).sum()} rays differ, first {rr[np.nonzero(~ok)[0][0]].tolist()}"
+    for got in (walk(gpu, rr), batch(gpu, rr)):
+        ok = same_hits(got, want)
+        assert ok.all(), f"{(~ok).sum()} rays differ, first {rr[np.nonzero(~ok)[0][0]].tolist()}"
     assert (idx >= 0).sum() > 30000
     # the same scene rendered: bounce rays start ON the grid
     want_bgr, want_acc, cn = osc.render(orc.RNG_STREAM, orc.MATH_PM, seed=3, samples_per_stream=4)

@@ -279,21 +279,6 @@ int rta_resolve(rta_context *ctx, const float *accum, int32_t width, int32_t hei
  * them.  Call with out == NULL to get the count. */
 int64_t rta_shard_pixels(int32_t width, int32_t height, int32_t shard_index, int32_t shard_count, int32_t *out);
 
-/* Device arithmetic probe for tests: out[i] = op(x[i], y[i]) evaluated on the
- * GPU with the kernels' own primitives.  op: 0 x/y, 1 sqrtf(x), 2 pm_sinf,
- * 3 pm_cosf, 4 pm_logf, 5 pm_powf(x,y), 6 fmaf(x,y,x), 7 x*y+x (unfused),
- * 8 the traversal's reciprocal-based quotient of x by y. */
-int rta_debug_arith(rta_context *ctx, int op, const float *x, const float *y, float *out, int64_t n);
-
-/* Measurement hook: closest hit as rta_trace_closest (variant 0) or with one
- * design decision changed - 1 traversal stack in private memory, 2 division-based
- * box test for every ray, 3 the reference's 32-byte node array with a node-number
- * stack, 4 two nested loops per ray instead of one, 5 struct-of-arrays nodes;
- * 100 and up: scheduling and
- * occupancy experiments listed in csrc/variants.hip.  Same results (100 returns
- * a census instead of hits); all but 0 take device pointers only. */
-int rta_debug_trace_variant(rta_context *ctx, int variant, const float *rays, int64_t n, rta_hit *hits, int mem);
-
 void *rta_stream(rta_context *ctx);     /* the hipStream_t all work of the context is enqueued on */
 
 #ifdef __cplusplus

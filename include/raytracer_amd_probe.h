@@ -1,0 +1,32 @@
+/* Probe entry points: measurement and test hooks exported by
+ * libraytracer_amd_probe.so, which works on contexts of libraytracer_amd.so and is
+ * not needed to render.  They have no counterpart in the reference. */
+#ifndef RAYTRACER_AMD_PROBE_H
+#define RAYTRACER_AMD_PROBE_H
+
+#include "raytracer_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Device arithmetic probe for tests: out[i] = op(x[i], y[i]) evaluated on the
+ * GPU with the kernels' own primitives.  op: 0 x/y, 1 sqrtf(x), 2 pm_sinf,
+ * 3 pm_cosf, 4 pm_logf, 5 pm_powf(x,y), 6 fmaf(x,y,x), 7 x*y+x (unfused),
+ * 8 the traversal's reciprocal-based quotient of x by y. */
+int rta_debug_arith(rta_context *ctx, int op, const float *x, const float *y, float *out, int64_t n);
+
+/* Measurement hook: closest hit as rta_trace_closest (variant 0) or with one
+ * design decision changed - 1 traversal stack in private memory, 2 division-based
+ * box test for every ray, 3 the reference's 32-byte node array with a node-number
+ * stack, 4 two nested loops per ray instead of one, 5 struct-of-arrays nodes;
+ * 100 and up: scheduling and
+ * occupancy experiments listed in csrc/variants.hip.  Same results (100 returns
+ * a census instead of hits); all but 0 take device pointers only. */
+int rta_debug_trace_variant(rta_context *ctx, int variant, const float *rays, int64_t n, rta_hit *hits, int mem);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

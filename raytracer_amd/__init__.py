@@ -15,6 +15,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libraytracer_amd.so")
+PROBE_LIB_PATH = os.path.join(_HERE, "libraytracer_amd_probe.so")
 CLI_PATH = os.path.join(_HERE, "raytracer")
 
 MEM_HOST, MEM_DEVICE = 0, 1
@@ -106,9 +107,13 @@ _SIGNATURES = {
     "rta_resolve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p,
                               C.c_int]),
     "rta_shard_pixels": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "rta_stream": (C.c_void_p, [C.c_void_p]),
+}
+
+# the probe library (include/raytracer_amd_probe.h): measurement and test hooks
+_PROBE_SIGNATURES = {
     "rta_debug_arith": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "rta_debug_trace_variant": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]),
-    "rta_stream": (C.c_void_p, [C.c_void_p]),
 }
 
 _lib = None
@@ -129,8 +134,31 @@ def lib():
     return _lib
 
 
+_probe = None
+
+
+def probe_lib():
+    """The probe library, loaded after the product library it works on."""
+    global _probe
+    if _probe is None:
+        lib()
+        if not os.path.exists(PROBE_LIB_PATH):
+            raise RuntimeError(f"{PROBE_LIB_PATH} not found: build it with `make` (hipcc, gfx950)")
+        handle = C.CDLL(PROBE_LIB_PATH)
+        for name, (res, args) in _PROBE_SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _probe = handle
+    return _probe
+
+
 def exported_symbols():
     return sorted(_SIGNATURES)
+
+
+def probe_symbols():
+    return sorted(_PROBE_SIGNATURES)
 
 
 def device_count():
@@ -360,7 +388,7 @@ class Context:
         self._check(lib().rta_trace_closest_static(self._h, rays_ptr, n, hits_ptr))
 
     def trace_variant_device(self, variant, rays_ptr, n, hits_ptr):
-        self._check(lib().rta_debug_trace_variant(self._h, variant, rays_ptr, n, hits_ptr, MEM_DEVICE))
+        self._check(probe_lib().rta_debug_trace_variant(self._h, variant, rays_ptr, n, hits_ptr, MEM_DEVICE))
 
     def trace_occluded(self, rays, tmax):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
@@ -413,5 +441,5 @@ class Context:
         x = np.ascontiguousarray(x, np.float32)
         y = np.ascontiguousarray(y if y is not None else np.ones_like(x), np.float32)
         out = np.empty_like(x)
-        self._check(lib().rta_debug_arith(self._h, ops[op], x.ctypes.data, y.ctypes.data, out.ctypes.data, x.size))
+        self._check(probe_lib().rta_debug_arith(self._h, ops[op], x.ctypes.data, y.ctypes.data, out.ctypes.data, x.size))
         return out

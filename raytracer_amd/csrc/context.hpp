@@ -114,6 +114,9 @@ struct rta_context {
 			return (ctx)->hip_fail(e__, #call);                             \
 	} while (0)
 
+// context.cpp: rta_trace_closest with the certified walk switched on or off
+extern "C" int rta_internal_trace_closest(rta_context *ctx, const float *rays, int64_t n, rta_hit *hits, int mem, int walk);
+
 namespace rta {
 
 // the uploaded tree as the kernels take it

@@ -1100,27 +1100,6 @@ __global__ __launch_bounds__(kBlock) void k_batch_occluded(const DeviceTree tree
 	    [&](uint32_t i, const HitRec &h) { flags[i] = h.prim >= 0 ? 1 : 0; });
 }
 
-__global__ __launch_bounds__(kBlock) void k_arith(int op, const float *x, const float *y, float *out, uint64_t n)
-{
-	const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-	if (i >= n)
-		return;
-	const float a = x[i], b = y[i];
-	float r;
-	switch (op) {
-	case 0: r = a / b; break;
-	case 1: r = __builtin_sqrtf(a); break;
-	case 2: r = pm_sinf(a); break;
-	case 3: r = pm_cosf(a); break;
-	case 4: r = pm_logf(a); break;
-	case 5: r = pm_powf(a, b); break;
-	case 6: r = __builtin_fmaf(a, b, a); break;
-	case 8: r = quotient(a, b, 1.f / b); break;
-	default: r = a * b + a; break;
-	}
-	out[i] = r;
-}
-
 }  // namespace
 
 // ------------------------------------------------------------------ launchers
@@ -1253,11 +1232,6 @@ void launch_batch_occluded(hipStream_t s, const TreeRef &tree, const float *rays
 {
 	hipLaunchKernelGGL(k_batch_occluded, dim3(batch_blocks(n)), dim3(kBlock), stack_bytes(depth), s, tree, rays, tmax, n,
 	                   out, depth, batch_rays_per_lane(n), order);
-}
-
-void launch_arith(hipStream_t s, int op, const float *x, const float *y, float *out, uint64_t n)
-{
-	hipLaunchKernelGGL(k_arith, dim3(blocks_for(n)), dim3(kBlock), 0, s, op, x, y, out, n);
 }
 
 }  // namespace rta

@@ -1,0 +1,71 @@
+// The probe library (libraytracer_amd_probe.so): measurement and test hooks that
+// work on a context of the product library but are no part of it - traversal
+// variants (variants.hip) and a device arithmetic probe.  Declared in
+// include/raytracer_amd_probe.h.
+#include <cstdint>
+
+#include "context.hpp"
+#include "probe.hpp"
+#include "raytracer_amd_probe.h"
+
+using namespace rta;
+
+extern "C" {
+
+int rta_debug_trace_variant(rta_context *ctx, int variant, const float *rays, int64_t n, rta_hit *hits, int mem)
+{
+	if (!ctx)
+		return RTA_E_INVALID;
+	if (variant == 0)
+		return rta_trace_closest(ctx, rays, n, hits, mem);
+	if (variant == 10)      // every ray through the replaying traversal, as scenes without a wide tree are traced
+		return rta_internal_trace_closest(ctx, rays, n, hits, mem, 0);
+	if (!ctx->have_scene)
+		return ctx->fail(RTA_E_NO_SCENE, "no scene uploaded");
+	if (variant == 20) {
+		if (!ctx->have_wide)
+			return ctx->fail(RTA_E_INVALID, "the scene has no wide tree");
+		if (n <= 0 || !rays || !hits || mem != RTA_MEM_DEVICE)
+			return ctx->fail(RTA_E_INVALID, "variant 20 takes device-resident ray batches");
+		HIP_TRY(ctx, hipSetDevice(ctx->device));
+		launch_wide_batch(ctx->stream, tree_of(ctx), rays, (uint64_t)n, hits, ctx->stack_depth);
+		HIP_TRY(ctx, hipGetLastError());
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		return RTA_OK;
+	}
+	if (variant < 1 || (variant > 5 && variant < 100) || variant > 360 || (variant >= 200 && variant - 200 < ctx->stack_depth) || n <= 0 || !rays || !hits || mem != RTA_MEM_DEVICE)
+		return ctx->fail(RTA_E_INVALID, "variants 1..4 take device-resident ray batches");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	if (variant == 5 && !ctx->have_soa) {
+		HIP_TRY(ctx, ctx->soa_nodes.reserve((size_t)ctx->n_pairs * 14 * 4));
+		launch_pairs_to_soa(ctx->stream, ctx->pairs.as<const float4>(), ctx->n_pairs, ctx->soa_nodes.as<float>());
+		ctx->have_soa = true;
+	}
+	launch_variant(ctx->stream, variant, tree_of(ctx), ctx->ref_nodes.as<const float4>(), ctx->soa_nodes.as<const float>(),
+	               ctx->n_pairs, rays, (uint64_t)n, hits, ctx->stack_depth);
+	HIP_TRY(ctx, hipGetLastError());
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return RTA_OK;
+}
+
+int rta_debug_arith(rta_context *ctx, int op, const float *x, const float *y, float *out, int64_t n)
+{
+	if (!ctx)
+		return RTA_E_INVALID;
+	if (n <= 0 || !x || !y || !out)
+		return ctx->fail(RTA_E_INVALID, "bad arguments");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	HIP_TRY(ctx, ctx->io_a.reserve((size_t)n * 4));
+	HIP_TRY(ctx, ctx->io_b.reserve((size_t)n * 4));
+	HIP_TRY(ctx, ctx->io_c.reserve((size_t)n * 4));
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->io_a.ptr, x, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->io_b.ptr, y, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+	launch_arith(ctx->stream, op, ctx->io_a.as<const float>(), ctx->io_b.as<const float>(), ctx->io_c.as<float>(),
+	             (uint64_t)n);
+	HIP_TRY(ctx, hipGetLastError());
+	HIP_TRY(ctx, hipMemcpyAsync(out, ctx->io_c.ptr, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return RTA_OK;
+}
+
+}  // extern "C"

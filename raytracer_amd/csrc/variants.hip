@@ -26,7 +26,8 @@
 
 #include <cstdlib>
 
-#include "kernels.hpp"
+#include "probe.hpp"
+#include "shading.hpp"
 #include "traverse.hpp"
 #include "traverse_wide.hpp"
 
@@ -394,6 +395,28 @@ __global__ __launch_bounds__(kBlock) void k_wide_redo(const DeviceTree tree, con
 	}
 }
 
+// out[i] = op(x[i], y[i]) with the kernels' own primitives (rta_debug_arith)
+__global__ __launch_bounds__(kBlock) void k_arith(int op, const float *x, const float *y, float *out, uint64_t n)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+	if (i >= n)
+		return;
+	const float a = x[i], b = y[i];
+	float r;
+	switch (op) {
+	case 0: r = a / b; break;
+	case 1: r = __builtin_sqrtf(a); break;
+	case 2: r = pm_sinf(a); break;
+	case 3: r = pm_cosf(a); break;
+	case 4: r = pm_logf(a); break;
+	case 5: r = pm_powf(a, b); break;
+	case 6: r = __builtin_fmaf(a, b, a); break;
+	case 8: r = quotient(a, b, 1.f / b); break;
+	default: r = a * b + a; break;
+	}
+	out[i] = r;
+}
+
 }  // namespace
 
 static int env_int(const char *name, int fallback)
@@ -478,6 +501,11 @@ void launch_variant(hipStream_t s, int variant, const TreeRef &tree, const float
 		                   hits, depth);
 		break;
 	}
+}
+
+void launch_arith(hipStream_t s, int op, const float *x, const float *y, float *out, uint64_t n)
+{
+	hipLaunchKernelGGL(k_arith, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, op, x, y, out, n);
 }
 
 }  // namespace rta

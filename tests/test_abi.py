@@ -14,10 +14,11 @@ import raytracer_amd as rta
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "raytracer_amd.h")
+PROBE_HEADER = os.path.join(ROOT, "include", "raytracer_amd_probe.h")
 
 
-def declared_functions():
-    with open(HEADER) as f:
+def declared_functions(header=HEADER):
+    with open(header) as f:
         text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
     return sorted(set(re.findall(r"\b(rta_[a-z_0-9]+)\s*\(", text)))
 
@@ -32,6 +33,16 @@ def test_every_declared_function_is_exported():
 
 def test_binding_covers_the_header():
     assert set(rta.exported_symbols()) == set(declared_functions())
+
+
+def test_probe_hooks_live_in_their_own_library():
+    """Measurement and test hooks are declared in a header of their own and exported by the probe library only."""
+    names = declared_functions(PROBE_HEADER)
+    assert set(names) == set(rta.probe_symbols()) and names
+    product, probe = C.CDLL(rta.LIB_PATH), C.CDLL(rta.PROBE_LIB_PATH)
+    for name in names:
+        assert hasattr(probe, name), f"{name} declared in the probe header but not exported"
+        assert not hasattr(product, name), f"{name} is a probe hook but the product library exports it"
 
 
 def test_struct_sizes_match_the_header(tmp_path):

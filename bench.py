@@ -250,7 +250,8 @@ def main():
         elapsed = time.perf_counter() - t0
         tot = {k: sum(st[k] for st in stats) for k in stats[0]}
         v = torch.tensor([elapsed, float(tot["rays"] + tot["shadow_rays"]), float(tot["samples"]),
-                          float(tot["rays"] - tot["early_rays"] + tot["shadow_rays"]), tot["gpu_ms"], float(tot["retraced_rays"])],
+                          float(tot["rays"] - tot["early_rays"] + tot["shadow_rays"]), tot["gpu_ms"], float(tot["retraced_rays"]),
+                          float(tot["walked_rays"])],
                          dtype=torch.float64, device=dev)
         if dist is not None:
             mx = v.clone()
@@ -258,9 +259,9 @@ def main():
             sm = v.clone()
             dist.all_reduce(sm, op=dist.ReduceOp.SUM)
             return dict(elapsed=float(mx[0]), queries=float(sm[1]), samples=float(sm[2]), traced=float(sm[3]),
-                        gpu_ms_max=float(mx[4]), spp=spp, retraced=float(sm[5]))
+                        gpu_ms_max=float(mx[4]), spp=spp, retraced=float(sm[5]), walked=float(sm[6]))
         return dict(elapsed=float(v[0]), queries=float(v[1]), samples=float(v[2]), traced=float(v[3]),
-                    gpu_ms_max=float(v[4]), spp=spp, retraced=float(v[5]))
+                    gpu_ms_max=float(v[4]), spp=spp, retraced=float(v[5]), walked=float(v[6]))
 
     spp_weak = spp_fixed * world
     main_run = run(spp_weak if args.scaling == "weak" else spp_fixed)
@@ -305,7 +306,9 @@ def main():
             "traced_mrays_per_s": m["traced_mrays_per_s"],
             "traced_fraction": main_run["traced"] / main_run["queries"],
             "retraced_rays_per_step": main_run["retraced"] / args.steps,
-            "traversal": "exact only" if args.exact_only else "certified walk over the wide tree for bounce rays, exact for the rest",
+            "walked_rays_per_step": main_run["walked"] / args.steps,
+            "traversal": ("certified walk over the wide tree for bounce rays, order-replaying traversal for the rest"
+                          if main_run["walked"] else "order-replaying traversal (no wide tree for this scene, or --exact-only)"),
             "samples_per_s": m["samples_per_s"],
             "n_gpus": world,
             "steps": args.steps,

@@ -246,6 +246,7 @@ typedef struct {
 	uint64_t retraced_rays;                 /* of `rays`: bounce rays whose walk over the wide tree could not prove its
 	                                         * answer (an exact tie, a hit on the rim of its leaf's box, ...) and that the
 	                                         * order-replaying traversal answered instead */
+	uint64_t walked_rays;                   /* of `rays`: handed to the walk over the wide tree (0 for scenes without one) */
 } rta_stats;
 
 /* The render loop.  Replaces src/main.cpp:657-714 (row loop, per-sample ray

@@ -1087,6 +1087,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 			st.tri_tests += c.tri;
 			st.sph_tests += c.sph;
 			st.retraced_rays += c.retraced;
+			st.walked_rays += c.walked;
 		}
 		// all groups are idle here (synchronised above)
 		if (d_frame && n_owned)

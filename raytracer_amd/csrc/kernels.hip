@@ -554,6 +554,8 @@ RTA_DEV void step_housekeeping(const RenderArgs &a, int par)
 		const uint32_t n = threadIdx.x % kRayKinds != (uint32_t)kDoubtRays ? a.cnt->n_ray[ray_queue_index(par, 0, 0) + threadIdx.x] : 0;
 		if (n)
 			atomicAdd(&a.cnt->rays, (unsigned long long)n);
+		if (n && a.wide_cap && threadIdx.x % kRayKinds == (uint32_t)kBounceRays)
+			atomicAdd(&a.cnt->walked, (unsigned long long)n);
 		a.cnt->n_ray[ray_queue_index(par ^ 1, 0, 0) + threadIdx.x] = 0;
 	}
 	if (threadIdx.x < kShards)

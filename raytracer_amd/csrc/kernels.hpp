@@ -29,6 +29,7 @@ struct Counters {
 	unsigned long long inner, tri, sph;     // RTA_RENDER_COUNT_WORK only
 	unsigned long long early;               // closest-hit queries answered where the ray was generated
 	unsigned long long retraced;            // closest-hit queries that the certified walk left to the exact traversal
+	unsigned long long walked;              // closest-hit queries handed to the certified walk (retraced ones included)
 };
 
 struct TreeRef {

@@ -161,10 +161,11 @@ def test_render_with_and_without_the_wide_tree(gpu):
     bgr_b, acc_b, st_b = gpu.render_scene(psc, seed=9, samples_per_stream=8, flags=rta.RENDER_EXACT_ONLY)
     assert np.array_equal(bits(acc_a), bits(acc_b)) and np.array_equal(bgr_a, bgr_b)
     assert st_a["rays"] == st_b["rays"] and st_a["early_rays"] == st_b["early_rays"]
-    assert st_b["retraced_rays"] == 0
+    assert st_b["retraced_rays"] == 0 and st_b["walked_rays"] == 0
     # the walk answers all but a sliver of the bounce rays itself
     bounce = st_a["rays"] - st_a["samples"]
     assert bounce > 100000 and st_a["retraced_rays"] < bounce // 1000
+    assert bounce * 0.99 <= st_a["walked_rays"] <= bounce      # all but the rays that need the division-based box test
 
 
 def test_scenes_without_a_wide_tree_render_as_before(gpu):
@@ -175,4 +176,4 @@ def test_scenes_without_a_wide_tree_render_as_before(gpu):
         walk(gpu, raygen.axis_rays())
     psc.set_render(64, 36, 4)
     _, _, st = gpu.render_scene(psc, seed=1, samples_per_stream=2)
-    assert st["retraced_rays"] == 0
+    assert st["retraced_rays"] == 0 and st["walked_rays"] == 0

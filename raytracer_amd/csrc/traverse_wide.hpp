@@ -40,7 +40,8 @@
 
 namespace rta {
 
-template <bool COUNT, int STRIDE = kBlock>
+// REL: the tree's entries carry entry-relative distance bits (DeviceTree::wide_relative)
+template <bool COUNT, bool REL, int STRIDE = kBlock>
 struct WideTraversal {
 	Ray ray;
 	V3 rcp, off;         // correctly rounded 1/direction; -(origin - scene centre) * rcp
@@ -89,7 +90,7 @@ struct WideTraversal {
 		doubt = !admitted;
 		node = admitted ? 0u : kWideNone;
 		t_enter = 0.f;
-		if (tree.wide_relative) {
+		if (REL) {
 			// (an estimate is enough: distance_bits() is monotonic whatever t_enter is)
 			const float ax = (tree.box_lo[0] - r.o.x) * rcp.x, bx = (tree.box_hi[0] - r.o.x) * rcp.x;
 			const float ay = (tree.box_lo[1] - r.o.y) * rcp.y, by = (tree.box_hi[1] - r.o.y) * rcp.y;
@@ -108,7 +109,7 @@ struct WideTraversal {
 	// down from the scene's size - and what remains of mantissa.
 	RTA_DEV uint32_t distance_bits(const DeviceTree &tree, float t, uint32_t dmask) const
 	{
-		if (tree.wide_relative) {
+		if (REL) {
 			const uint32_t x = __float_as_uint(__builtin_fmaxf(t - t_enter, 0.f));
 			const uint32_t k = (x > tree.wide_key_base ? x : tree.wide_key_base) - tree.wide_key_base;
 			return ((k < 0x07ffffffu ? k : 0x07ffffffu) << 4) & dmask;
@@ -164,7 +165,8 @@ struct WideTraversal {
 		const float xz = __builtin_fmaf(RTA_WIDE_HALF(fz##pair, part), rcp.z, off.z);             \
 		const float t0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(ex, ey), ez), 0.f);      \
 		const float t1 = __builtin_fminf(__builtin_fminf(__builtin_fminf(xx, xy), xz), reach);    \
-		key[s] = t0 <= t1 ? (ref | distance_bits(tree, t0, dmask)) : 0xffffffffu;                 \
+		const uint32_t hit_key = ref | distance_bits(tree, t0, dmask);                             \
+		key[s] = t0 <= t1 ? hit_key : 0xffffffffu;                                                \
 	}
 		RTA_WIDE_CHILD(0, 01, x, refs.x)
 		RTA_WIDE_CHILD(1, 01, y, refs.y)
@@ -284,11 +286,11 @@ struct WideCensus {
 	uint32_t trips, visit_runs, visit_lanes, test_runs, test_lanes;
 };
 
-template <bool COUNT, class Grab, class Load, class Store>
-RTA_DEV void traverse_wide_pulling(const DeviceTree &tree, const uint32_t refill_at, const uint32_t quorum,
+template <bool COUNT, bool REL, class Grab, class Load, class Store>
+RTA_DEV void traverse_wide_pulling_as(const DeviceTree &tree, const uint32_t refill_at, const uint32_t quorum,
                                    const uint32_t waiting_quorum, uint32_t *stack, const int cap, WorkCount &work, WideCensus &census, Grab grab, Load load, Store store)
 {
-	WideTraversal<COUNT> tr;
+	WideTraversal<COUNT, REL> tr;
 	tr.rest(cap);
 	uint32_t tag = 0;
 	bool loaded = false, dry = false;
@@ -348,6 +350,17 @@ RTA_DEV void traverse_wide_pulling(const DeviceTree &tree, const uint32_t refill
 	if (loaded)
 		tr.certify(tree);
 	store(loaded, tag, tr.result(), tr.doubt != 0);
+}
+
+// The loop exists twice, once per kind of distance bits: the choice is the tree's, made once per wave.
+template <bool COUNT, class Grab, class Load, class Store>
+RTA_DEV void traverse_wide_pulling(const DeviceTree &tree, const uint32_t refill_at, const uint32_t quorum,
+                                   const uint32_t waiting_quorum, uint32_t *stack, const int cap, WorkCount &work, WideCensus &census, Grab grab, Load load, Store store)
+{
+	if (tree.wide_relative)
+		traverse_wide_pulling_as<COUNT, true>(tree, refill_at, quorum, waiting_quorum, stack, cap, work, census, grab, load, store);
+	else
+		traverse_wide_pulling_as<COUNT, false>(tree, refill_at, quorum, waiting_quorum, stack, cap, work, census, grab, load, store);
 }
 
 }  // namespace rta

@@ -390,6 +390,9 @@ class Context:
     def trace_variant_device(self, variant, rays_ptr, n, hits_ptr):
         self._check(probe_lib().rta_debug_trace_variant(self._h, variant, rays_ptr, n, hits_ptr, MEM_DEVICE))
 
+    def trace_occluded_device(self, rays_ptr, tmax_ptr, n, out_ptr):
+        self._check(lib().rta_trace_occluded(self._h, rays_ptr, tmax_ptr, n, out_ptr, MEM_DEVICE))
+
     def trace_occluded(self, rays, tmax):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
         tmax = np.ascontiguousarray(tmax, np.float32)

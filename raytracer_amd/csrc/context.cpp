@@ -593,7 +593,11 @@ int rta_trace_occluded(rta_context *ctx, const float *rays, const float *tmax, i
 	const uint32_t *order = nullptr;
 	if (int rc = tracing_order(ctx, d_rays, n, order))
 		return rc;
-	launch_batch_occluded(ctx->stream, tree_of(ctx), d_rays, d_tmax, (uint64_t)n, d_out, ctx->stack_depth, order);
+	static const bool exact_only = getenv("RTA_BATCH_EXACT") != nullptr;      // measurement: price the walk
+	if (ctx->have_wide && n < ((int64_t)1 << 32) && !exact_only)
+		launch_batch_occluded_walk(ctx->stream, tree_of(ctx), d_rays, d_tmax, (uint64_t)n, d_out, kBatchWalkCap, ctx->stack_depth, order);
+	else
+		launch_batch_occluded(ctx->stream, tree_of(ctx), d_rays, d_tmax, (uint64_t)n, d_out, ctx->stack_depth, order);
 	HIP_TRY(ctx, hipGetLastError());
 	if (mem == RTA_MEM_HOST)
 		HIP_TRY(ctx, hipMemcpyAsync(out, d_out, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));

@@ -748,6 +748,85 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 		count_flush(a.cnt, wc);
 }
 
+// Occlusion queries of one wave by the any-hit walk over the wide tree (traverse_wide.hpp).
+//   tag = load(i, ray, limit)    the wave's i-th query
+//   fetch(tag, ray, limit)       the same query again, by its tag
+//   done(tag, occluded)          its answer
+// A query that the walk cannot answer for certain is traced by the replaying traversal on the
+// spot, by the lanes that have just finished (their LDS columns are empty; `stack` must hold
+// max(cap, depth) entries per lane): such queries are too rare for a queue of their own.
+constexpr uint32_t kShadowWalkRefillAt = 24, kShadowWalkQuorum = 24, kShadowWalkWaiting = 64;
+
+template <class Grab, class Load, class Fetch, class Done>
+RTA_DEV void occluded_by_walk(const DeviceTree &tree, uint32_t *stack, const int cap, const int depth, Grab grab, Load load,
+                              Fetch fetch, Done done)
+{
+	WorkCount wc = {0, 0, 0};
+	WideCensus cs = {0, 0, 0, 0, 0};
+	traverse_wide_pulling<false, true>(
+	    tree, kShadowWalkRefillAt, kShadowWalkQuorum, kShadowWalkWaiting, stack, cap, wc, cs, grab, load,
+	    [&](bool finished, uint32_t tag, const HitRec &h, bool doubt) {
+		    bool occluded = h.prim >= 0;
+		    const bool again = finished && doubt;
+		    if (__ballot(again)) {
+			    Traversal<true, false> tr;
+			    tr.rest();
+			    if (again) {
+				    Ray ray;
+				    float limit;
+				    fetch(tag, ray, limit);
+				    tr.start(tree, ray, limit);
+			    }
+			    while (__ballot(tr.more)) {
+				    if (tr.more)
+					    tr.step(tree, stack, depth, wc);
+			    }
+			    if (again)
+				    occluded = tr.result().prim >= 0;
+		    }
+		    if (finished)
+			    done(tag, occluded);
+	    });
+}
+
+// k_shadow for scenes with a wide tree: a wave takes 64 consecutive queue entries through the any-hit walk.
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_shadow_walk(const RenderArgs a, const int depth)
+{
+	extern __shared__ uint32_t lds_stack[];
+	const uint32_t n = a.cnt->n_shadow;
+	if (blockIdx.x == 0 && threadIdx.x == 0)
+		atomicAdd(&a.cnt->shadow_rays, (unsigned long long)n);
+	const uint32_t begin = (blockIdx.x * (kBlock / 64) + threadIdx.x / 64) * 64;
+	if (begin >= n)
+		return;
+	const auto fetch = [&](uint32_t i, Ray &ray, float &limit) {
+		const float4 *e = a.shadow + 3 * (size_t)i;
+		const float4 e0 = e[0], e1 = e[1];
+		ray = Ray{xyz(e0), xyz(e1)};
+		limit = e0.w;
+	};
+	occluded_by_walk(
+	    a.tree, lds_stack + threadIdx.x, (int)a.wide_cap, depth, OwnChunk{n - begin < 64u ? n - begin : 64u, 0u},
+	    [&](uint32_t i, Ray &ray, float &limit) {
+		    fetch(begin + i, ray, limit);
+		    return begin + i;
+	    },
+	    fetch,
+	    [&](uint32_t i, bool occluded) {
+		    if (!occluded) {
+			    // src/main.cpp:569: the light's contribution joins the path radiance
+			    const float4 *e = a.shadow + 3 * (size_t)i;
+			    const float4 e1 = e[1], e2 = e[2];
+			    const uint32_t slot = __float_as_uint(e1.w);
+			    float4 C = a.col[slot];
+			    C.x += e2.x;
+			    C.y += e2.y;
+			    C.z += e2.z;
+			    a.col[slot] = C;
+		    }
+	    });
+}
+
 // ------------------------------------------------------------------ item weights
 
 // How expensive will the parts of the tiles be?  One ray through the centre of
@@ -1102,6 +1181,32 @@ __global__ __launch_bounds__(kBlock) void k_batch_occluded(const DeviceTree tree
 	    [&](uint32_t i, const HitRec &h) { flags[i] = h.prim >= 0 ? 1 : 0; });
 }
 
+// k_batch_occluded by the any-hit walk over the wide tree.
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_batch_occluded_walk(
+    const DeviceTree tree, const float *rays, const float *tmax, uint64_t n, uint8_t *out, const int cap, const int depth,
+    const uint32_t rays_per_lane, const uint32_t *order)
+{
+	extern __shared__ uint32_t lds_stack[];
+	const uint64_t per_wave = 64 * (uint64_t)rays_per_lane;
+	const uint64_t begin = ((uint64_t)blockIdx.x * (kBlock / 64) + threadIdx.x / 64) * per_wave;
+	if (begin >= n)
+		return;
+	const uint32_t *which = order ? order + begin : nullptr;
+	const auto fetch = [&](uint32_t number, Ray &ray, float &limit) {
+		const float *r = rays + (size_t)number * 6;
+		ray = Ray{mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5])};
+		limit = tmax[number];
+	};
+	occluded_by_walk(
+	    tree, lds_stack + threadIdx.x, cap, depth, OwnChunk{(uint32_t)(n - begin < per_wave ? n - begin : per_wave), 0u},
+	    [&](uint32_t i, Ray &ray, float &limit) {
+		    const uint32_t number = which ? which[i] : (uint32_t)begin + i;
+		    fetch(number, ray, limit);
+		    return number;
+	    },
+	    fetch, [&](uint32_t number, bool occluded) { out[number] = occluded ? 1 : 0; });
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------ launchers
@@ -1185,7 +1290,10 @@ void launch_intersect(hipStream_t s, const RenderArgs &a, int par, int depth, bo
 
 void launch_shadow(hipStream_t s, const RenderArgs &a, uint32_t bound, int depth, bool count)
 {
-	if (count && a.leafwise)
+	if (a.wide_cap && !count)
+		hipLaunchKernelGGL(k_shadow_walk, dim3(blocks_for(bound)), dim3(kBlock), stack_bytes(std::max(depth, (int)a.wide_cap)), s, a,
+		                   depth);
+	else if (count && a.leafwise)
 		hipLaunchKernelGGL((k_shadow<true, true>), dim3(blocks_for(bound)), dim3(kBlock), stack_bytes(depth), s, a, depth);
 	else if (count)
 		hipLaunchKernelGGL((k_shadow<true, false>), dim3(blocks_for(bound)), dim3(kBlock), stack_bytes(depth), s, a, depth);
@@ -1227,6 +1335,14 @@ void launch_batch_walk(hipStream_t s, const TreeRef &tree, const float *rays, ui
 	(void)hipMemsetAsync(n_doubts, 0, sizeof(uint32_t), s);
 	hipLaunchKernelGGL(k_batch_walk, dim3(blocks_for((n + rays_per_lane - 1) / rays_per_lane)), dim3(kBlock), stack_bytes(cap), s,
 	                   tree, rays, n, hits, cap, rays_per_lane, order, doubts, n_doubts);
+}
+
+void launch_batch_occluded_walk(hipStream_t s, const TreeRef &tree, const float *rays, const float *tmax, uint64_t n,
+                                uint8_t *out, int cap, int depth, const uint32_t *order)
+{
+	const uint32_t rays_per_lane = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, n >> 20));
+	hipLaunchKernelGGL(k_batch_occluded_walk, dim3(blocks_for((n + rays_per_lane - 1) / rays_per_lane)), dim3(kBlock),
+	                   stack_bytes(std::max(cap, depth)), s, tree, rays, tmax, n, out, cap, depth, rays_per_lane, order);
 }
 
 void launch_batch_occluded(hipStream_t s, const TreeRef &tree, const float *rays, const float *tmax, uint64_t n,

@@ -154,6 +154,9 @@ void launch_batch_closest(hipStream_t s, const TreeRef &tree, const float *rays,
 // the certified walk over the wide tree; rays left in doubt are listed for launch_batch_closest (order = doubts)
 void launch_batch_walk(hipStream_t s, const TreeRef &tree, const float *rays, uint64_t n, rta_hit *hits, int cap,
                        const uint32_t *order, uint32_t *doubts, uint32_t *n_doubts);
+// the any-hit walk over the wide tree (n < 2^32); queries it cannot answer for certain are traced exactly in the same launch
+void launch_batch_occluded_walk(hipStream_t s, const TreeRef &tree, const float *rays, const float *tmax, uint64_t n,
+                                uint8_t *out, int cap, int depth, const uint32_t *order);
 void launch_batch_occluded(hipStream_t s, const TreeRef &tree, const float *rays, const float *tmax, uint64_t n,
                            uint8_t *out, int depth, const uint32_t *order = nullptr);
 // sort_rays.hip: the tracing order of a big batch (by origin cell and direction octant)

@@ -40,8 +40,15 @@
 
 namespace rta {
 
-// REL: the tree's entries carry entry-relative distance bits (DeviceTree::wide_relative)
-template <bool COUNT, bool REL, int STRIDE = kBlock>
+// REL: the tree's entries carry entry-relative distance bits (DeviceTree::wide_relative).
+//
+// ANY: the occlusion query of src/main.cpp:424-478 instead - is any primitive hit before `limit`?
+// The reference answers yes as soon as a leaf it reaches holds a primitive with t < limit, and it
+// reaches a leaf when the leaf's box and all boxes above pass its test against `limit`; the order
+// plays no part.  The walk's "no" is therefore always the reference's (by step 1 it tested every
+// triangle that is accepted before `limit`), and its "yes" is once the hit triangle's leaf box
+// passes the reference's test (step 3).  `best` stays at `limit` throughout.
+template <bool COUNT, bool REL, bool ANY = false, int STRIDE = kBlock>
 struct WideTraversal {
 	Ray ray;
 	V3 rcp, off;         // correctly rounded 1/direction; -(origin - scene centre) * rcp
@@ -71,14 +78,14 @@ struct WideTraversal {
 		t_enter = 0.f;
 	}
 
-	RTA_DEV void start(const DeviceTree &tree, const Ray &r, const int cap)
+	RTA_DEV void start(const DeviceTree &tree, const Ray &r, const int cap, const float limit = FLT_MAX)
 	{
 		ray = r;
 		rcp = mk(1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z);
 		const V3 from = r.o - mk(tree.wide_center[0], tree.wide_center[1], tree.wide_center[2]);
 		off = mk(-(from.x * rcp.x), -(from.y * rcp.y), -(from.z * rcp.z));
 		negative = (__float_as_uint(r.d.x) >> 31) | ((__float_as_uint(r.d.y) >> 31) << 1) | ((__float_as_uint(r.d.z) >> 31) << 2);
-		best = FLT_MAX;
+		best = ANY ? limit : FLT_MAX;
 		prim = -1;
 		u = v = 0.f;
 		tie = false;
@@ -246,7 +253,14 @@ struct WideTraversal {
 		const float4 p0 = rec[0], p1 = rec[1], p2 = rec[2];
 		float tu = 0, tv = 0;
 		const float t = test_triangle(mk(p0.x, p0.y, p0.z), mk(p1.x, p1.y, p1.z), mk(p2.x, p2.y, p2.z), ray, tu, tv);
-		if (t < best) {
+		if (ANY) {
+			if (t < best) {       // an occluder: the walk is over, certify() has the last word
+				prim = (int32_t)i;
+				node = kWideNone;
+				sp = 0;
+				lp = cap;
+			}
+		} else if (t < best) {
 			best = t;
 			prim = (int32_t)i;
 			u = tu;
@@ -276,7 +290,7 @@ struct WideTraversal {
 
 // A wave works through more rays than it has lanes (as traverse_pulling).
 //   got = grab(want, first)                  reserves up to `want` rays
-//   tag = load(i, ray)                       fetches ray number i
+//   tag = load(i, ray)                       fetches ray number i (ANY: load(i, ray, limit))
 //   store(finished, tag, hit, doubt)         called by ALL lanes of the wave together; `finished` lanes
 //                                            hand in their ray's result, or `doubt`: trace it exactly
 // `quorum`: lanes with a listed triangle that make the wave run the triangle test; `waiting_quorum`: lanes
@@ -286,11 +300,11 @@ struct WideCensus {
 	uint32_t trips, visit_runs, visit_lanes, test_runs, test_lanes;
 };
 
-template <bool COUNT, bool REL, class Grab, class Load, class Store>
+template <bool COUNT, bool REL, bool ANY, class Grab, class Load, class Store>
 RTA_DEV void traverse_wide_pulling_as(const DeviceTree &tree, const uint32_t refill_at, const uint32_t quorum,
                                    const uint32_t waiting_quorum, uint32_t *stack, const int cap, WorkCount &work, WideCensus &census, Grab grab, Load load, Store store)
 {
-	WideTraversal<COUNT, REL> tr;
+	WideTraversal<COUNT, REL, ANY> tr;
 	tr.rest(cap);
 	uint32_t tag = 0;
 	bool loaded = false, dry = false;
@@ -310,8 +324,14 @@ RTA_DEV void traverse_wide_pulling_as(const DeviceTree &tree, const uint32_t ref
 			    __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
 			if (!tr.busy(cap) && rank < got) {
 				Ray ray;
-				tag = load(first + rank, ray);
-				tr.start(tree, ray, cap);
+				if constexpr (ANY) {
+					float limit;
+					tag = load(first + rank, ray, limit);
+					tr.start(tree, ray, cap, limit);
+				} else {
+					tag = load(first + rank, ray);
+					tr.start(tree, ray, cap);
+				}
 				loaded = true;
 			}
 		}
@@ -353,14 +373,14 @@ RTA_DEV void traverse_wide_pulling_as(const DeviceTree &tree, const uint32_t ref
 }
 
 // The loop exists twice, once per kind of distance bits: the choice is the tree's, made once per wave.
-template <bool COUNT, class Grab, class Load, class Store>
+template <bool COUNT, bool ANY = false, class Grab, class Load, class Store>
 RTA_DEV void traverse_wide_pulling(const DeviceTree &tree, const uint32_t refill_at, const uint32_t quorum,
                                    const uint32_t waiting_quorum, uint32_t *stack, const int cap, WorkCount &work, WideCensus &census, Grab grab, Load load, Store store)
 {
 	if (tree.wide_relative)
-		traverse_wide_pulling_as<COUNT, true>(tree, refill_at, quorum, waiting_quorum, stack, cap, work, census, grab, load, store);
+		traverse_wide_pulling_as<COUNT, true, ANY>(tree, refill_at, quorum, waiting_quorum, stack, cap, work, census, grab, load, store);
 	else
-		traverse_wide_pulling_as<COUNT, false>(tree, refill_at, quorum, waiting_quorum, stack, cap, work, census, grab, load, store);
+		traverse_wide_pulling_as<COUNT, false, ANY>(tree, refill_at, quorum, waiting_quorum, stack, cap, work, census, grab, load, store);
 }
 
 }  // namespace rta

@@ -67,7 +67,7 @@ def _grid_mesh(n, z_of):
 
 def _mesh_scene(tris):
     body = " ".join("%r" % float(x) for x in tris.reshape(-1))
-    return ("render {\n\tcamera [0.5 0.5 3]\n\tlook_at [0.5 0.5 0]\n\tup [0 1 0]\n\twidth 48\n\theight 48\n\tsamples 8\n"
+    return ("render {\n\tcamera [0.5 0.5 3]\n\tlook_at [0.5 0.5 0]\n\tup [0 1 0]\n\twidth 48\n\theight 48\n\tsamples 8\n\tfov 30\n"
             "\tsky_box_color [.5 .6 1]\n}\n\nmaterial {\n\tcolor [0.8 0.7 0.6]\n\troughness 1\n}\n\n"
             "triangle_mesh {\n\tvertices [ %s ]\n}\n" % body)
 
@@ -104,6 +104,20 @@ def test_walk_equals_the_order_replaying_traversal_on_the_dragon(gpu):
         for how, got in (("probe", walk(gpu, rr)), ("rta_trace_closest", batch(gpu, rr))):
             ok = same_hits(got, want)
             assert ok.all(), f"{label} ({how}): {(~ok).sum()} rays differ, first {rr[np.nonzero(~ok)[0][0]].tolist()}"
+    # occlusion queries take the any-hit walk: limits below, at and beyond the nearest hit, and the checker's answers
+    for label, rr in (("inside", inside[:150000]), ("bounce", bounce[:150000]), ("aimed at vertices", aimed), ("far", far),
+                      ("long", long_dir), ("odd", odd)):
+        near = exact(gpu, rr)["t"]
+        k = rng.integers(0, 6, rr.shape[0])
+        scale = np.float32([0.5, 0.999, 1.0, 1.0000001, 1.5, 1e30])[k]
+        with np.errstate(over="ignore"):
+            limit = np.where(near < 3e38, near * scale, np.float32(10.0) * scale).astype(np.float32)
+        limit[k == 5] = np.float32(3.4e38)
+        want = osc.trace_occluded(rr, limit)
+        got = gpu.trace_occluded(rr, limit)
+        assert np.array_equal(got, want), f"occlusion, {label}: {(got != want).sum()} answers differ"
+        if label in ("inside", "bounce", "aimed at vertices"):
+            assert 0.1 < want.mean() < 0.9
     # and the exact traversal is the checker's (a sample; tests/test_gpu_parity.py covers it at length)
     sample = np.concatenate([bounce[:20000], aimed[:20000]])
     idx, t, u, v = osc.trace_closest(sample)
@@ -144,6 +158,11 @@ def test_ties_and_flat_boxes_are_handed_on(gpu, shape):
         ok = same_hits(got, want)
         assert ok.all(), f"{(~ok).sum()} rays differ, first {rr[np.nonzero(~ok)[0][0]].tolist()}"
     assert (idx >= 0).sum() > 30000
+    # occlusion along the same rays: limits at, just below and just beyond the hit (ties and flat boxes again)
+    k = rng.integers(0, 5, rr.shape[0])
+    with np.errstate(over="ignore"):
+        limit = np.where(idx >= 0, t * np.float32([0.75, 0.9999999, 1.0, 1.0000001, 2.0])[k], np.float32(5.0)).astype(np.float32)
+    assert np.array_equal(gpu.trace_occluded(rr, limit), osc.trace_occluded(rr, limit))
     # the same scene rendered: bounce rays start ON the grid
     want_bgr, want_acc, cn = osc.render(orc.RNG_STREAM, orc.MATH_PM, seed=3, samples_per_stream=4)
     bgr, acc, st = gpu.render_scene(psc, seed=3, samples_per_stream=4)
@@ -177,3 +196,24 @@ def test_scenes_without_a_wide_tree_render_as_before(gpu):
     psc.set_render(64, 36, 4)
     _, _, st = gpu.render_scene(psc, seed=1, samples_per_stream=2)
     assert st["retraced_rays"] == 0 and st["walked_rays"] == 0
+
+
+def test_shadow_rays_take_the_any_hit_walk(gpu):
+    """A triangle-only scene with a light: next-event estimation queues occlusion queries, which the any-hit walk
+    answers (scenes with a wide tree); sums and image bytes are the checker's, with and without the wide tree."""
+    tris = _grid_mesh(16, lambda x, y: 0.15 * np.sin(6 * x) * np.cos(4 * y))
+    body = " ".join("%r" % float(x) for x in tris.reshape(-1))
+    text = ("render {\n\tcamera [0.5 0.5 2.5]\n\tlook_at [0.5 0.5 0]\n\tup [0 1 0]\n\twidth 64\n\theight 48\n\tsamples 32\n\tfov 25\n"
+            "\tsky_box_color [.05 .06 .1]\n}\n\nmaterial {\n\tcolor [0.8 0.7 0.6]\n\troughness 1\n}\n\n"
+            "triangle_mesh {\n\tvertices [ %s ]\n}\n\n"
+            "material {\n\tcolor [0 0 0]\n\troughness 1\n}\n\narea_light {\n\tcolor [12 11 9]\n}\n\n"
+            "triangle_mesh {\n\tvertices [ 0.3 0.3 1.2  0.7 0.3 1.2  0.5 0.7 1.3   0.1 0.9 0.9  0.3 0.9 0.9  0.2 0.7 1.0 ]\n}\n" % body)
+    osc = orc.Scene.parse(text).build_bvh()
+    psc = rta.Scene.parse(text).build_bvh()
+    gpu.upload(psc)
+    want_bgr, want_acc, cn = osc.render(orc.RNG_STREAM, orc.MATH_PM, seed=5, samples_per_stream=4)
+    for flags in (0, rta.RENDER_EXACT_ONLY):
+        bgr, acc, st = gpu.render_scene(psc, seed=5, samples_per_stream=4, flags=flags)
+        assert st["rays"] == cn["rays"] and st["shadow_rays"] == cn["shadow_rays"] and st["shadow_rays"] > 10000
+        assert np.array_equal(bits(acc), bits(want_acc)) and np.array_equal(bgr, want_bgr)
+        assert (st["walked_rays"] > 0) == (flags == 0)

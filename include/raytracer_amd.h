@@ -226,8 +226,9 @@ enum {
 	RTA_RENDER_COUNT_WORK = 2,     /* count node visits / primitive tests (slower kernels) */
 	RTA_RENDER_SMALL_PASSES = 4,   /* hold as few sample blocks in memory at a time as possible (see rta_render) */
 	RTA_RENDER_EXACT_ONLY = 8      /* every ray through the traversal that replays the reference's visit order; without it
-	                                * bounce rays of triangle scenes walk a second, 4-wide tree in any order and are answered
-	                                * from that walk only where it proves NearestHit's result (same bits either way) */
+	                                * bounce rays and occlusion queries of triangle scenes walk a second, 4-wide tree in any
+	                                * order and are answered from that walk only where it proves NearestHit's / Occluded's
+	                                * result (same bits either way) */
 };
 
 typedef struct {

@@ -539,10 +539,14 @@ int rta_internal_trace_closest(rta_context *ctx, const float *rays, int64_t n, r
 		return rc;
 	static const bool exact_only = getenv("RTA_BATCH_EXACT") != nullptr;      // measurement: price the walk
 	static const int cap = getenv("RTA_BATCH_CAP") ? atoi(getenv("RTA_BATCH_CAP")) : kBatchWalkCap;
+	// the list of the rays the walk hands on: 4 bytes per ray; without room for it the batch is traced as before
+	const size_t list_bytes = ((size_t)n * 4 + 255) & ~(size_t)255;
+	if (walk && ctx->have_wide && n < ((int64_t)1 << 32) && !exact_only && ctx->doubts.reserve(list_bytes + 256) != hipSuccess) {
+		(void)hipGetLastError();
+		walk = false;
+	}
 	if (walk && ctx->have_wide && n < ((int64_t)1 << 32) && !exact_only) {
 		// the certified walk answers what it can prove; the rest goes through the replaying traversal
-		const size_t list_bytes = ((size_t)n * 4 + 255) & ~(size_t)255;
-		HIP_TRY(ctx, ctx->doubts.reserve(list_bytes + 256));
 		uint32_t *list = ctx->doubts.as<uint32_t>(), *count = (uint32_t *)(ctx->doubts.as<char>() + list_bytes);
 		launch_batch_walk(ctx->stream, tree_of(ctx), d_rays, (uint64_t)n, d_hits, cap, order, list, count);
 		HIP_TRY(ctx, hipGetLastError());

@@ -446,6 +446,7 @@ int rta_upload_scene(rta_context *ctx, const rta_scene_desc *desc)
 			return rc;
 		memcpy(ctx->wide_center, wide.center, 12);
 		ctx->wide_reach2 = wide.reach * wide.reach * (1.f - 0x1p-20f);
+		ctx->wide_reach = wide.reach;
 		ctx->wide_depth = wide.depth;
 		ctx->wide_index_mask = wide.index_mask;
 		ctx->wide_span = wide.span;
@@ -779,6 +780,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	HIP_TRY(ctx, ctx->rng.reserve(S * 4));
 	HIP_TRY(ctx, ctx->acc.reserve(S * 16));
 	HIP_TRY(ctx, ctx->meta.reserve(S * 16));
+	HIP_TRY(ctx, ctx->hint.reserve(S * 4));
 	// per group: 2 parities x kRayKinds kinds x kShards sub-queues, each able to take
 	// everything its share of the group's workgroups can append in one launch
 	const uint32_t shard_cap = (uint32_t)((group_blocks + kShards - 1) / kShards) * 256;
@@ -861,6 +863,19 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	// Bounce rays take the certified walk over the wide tree where the scene has one (triangles
 	// only, short leaves); 20 LDS entries per lane keep 8 workgroups on a CU
 	base.wide_cap = (ctx->have_wide && !base.leafwise && !(p->flags & RTA_RENDER_EXACT_ONLY)) ? 20u : 0u;
+	// Camera rays join them when the camera (a pinhole) lies within the wide tree's reach; each starts
+	// with the triangle that the slot's last camera ray hit: the same pixel, most often the same triangle
+	{
+		double d2 = 0;
+		for (int k = 0; k < 3; k++)
+			d2 += ((double)camera->origin[k] - ctx->wide_center[k]) * ((double)camera->origin[k] - ctx->wide_center[k]);
+		static const char *camera_walk = getenv("RTA_CAMERA_WALK"), *hints = getenv("RTA_HINTS");      // measurement
+		base.camera_walk = base.wide_cap && !(camera->defocus_angle > 0.f) && d2 < 0.99 * (double)ctx->wide_reach * ctx->wide_reach &&
+		                           (camera_walk ? atoi(camera_walk) != 0 : true)
+		                       ? 1u
+		                       : 0u;
+		base.hint = base.camera_walk && (hints ? atoi(hints) != 0 : true) ? ctx->hint.as<int32_t>() : nullptr;
+	}
 	base.rays_per_lane = 8;       // measured on dragon.txt: 4 and 12 lose 1-2 %
 	base.refill_at = 24;          // likewise 16 (8 loses 3 %)
 
@@ -878,6 +893,8 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		a.rng = ctx->rng.as<uint32_t>() + off;
 		a.acc = ctx->acc.as<float4>() + off;
 		a.meta = ctx->meta.as<uint4>() + off;
+		if (base.hint)
+			a.hint = base.hint + off;
 		a.shadow = ctx->shadow.as<float4>() ? ctx->shadow.as<float4>() + 3 * off : nullptr;
 		a.q_ray = ctx->q_ray.as<uint32_t>() + (size_t)g * group_queue;
 		a.q_bounce = ctx->q_bounce.as<float4>() + (size_t)g * group_bounce;

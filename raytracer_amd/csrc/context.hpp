@@ -56,7 +56,7 @@ struct rta_context {
 	rta::DeviceBuffer pairs, prims, shade_prims, materials, lights, ref_nodes;
 	rta::DeviceBuffer wide_nodes, leaf_boxes;     // the 4-wide tree of the certified traversal (wide_tree.hpp)
 	bool have_wide = false;
-	float wide_center[3] = {0, 0, 0}, wide_reach2 = 0;
+	float wide_center[3] = {0, 0, 0}, wide_reach2 = 0, wide_reach = 0;
 	int wide_depth = 0;
 	uint32_t wide_index_mask = 0;
 	float wide_span = 1;
@@ -71,7 +71,7 @@ struct rta_context {
 	int32_t n_prims = 0, n_lights = 0;
 
 	// wavefront workspace
-	rta::DeviceBuffer ray0, ray1, hit, thr, col, rng, acc, meta, q_ray, q_bounce, shadow, partial, pixels, frame, bgr, counters;
+	rta::DeviceBuffer ray0, ray1, hit, thr, col, rng, acc, meta, hint, q_ray, q_bounce, shadow, partial, pixels, frame, bgr, counters;
 	rta::DeviceBuffer part_weights, part_order;
 	rta::DeviceBuffer cover, sky_map;         // see k_sky_map
 	rta::DeviceBuffer ray_order;              // see tracing_order

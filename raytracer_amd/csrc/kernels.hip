@@ -257,6 +257,8 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 			const float4 s0 = a.shade_prims[3 * (size_t)prim];
 			const float4 s1 = a.shade_prims[3 * (size_t)prim + 1];
 			const float4 s2 = a.shade_prims[3 * (size_t)prim + 2];
+			if (a.hint && bounce == 0)
+				a.hint[slot] = prim;      // the slot's next camera ray goes through the same pixel
 			const int32_t mat_id = __float_as_int(s0.w), light_id = __float_as_int(s1.w);
 			const bool is_sphere = __float_as_int(s2.w) == RTA_PRIM_SPHERE;
 
@@ -554,12 +556,12 @@ RTA_DEV void step_housekeeping(const RenderArgs &a, int par)
 		const uint32_t n = threadIdx.x % kRayKinds != (uint32_t)kDoubtRays ? a.cnt->n_ray[ray_queue_index(par, 0, 0) + threadIdx.x] : 0;
 		if (n)
 			atomicAdd(&a.cnt->rays, (unsigned long long)n);
-		if (n && a.wide_cap && threadIdx.x % kRayKinds == (uint32_t)kBounceRays)
+		if (n && a.wide_cap && (threadIdx.x % kRayKinds == (uint32_t)kBounceRays || (a.camera_walk && threadIdx.x % kRayKinds == (uint32_t)kCameraRays)))
 			atomicAdd(&a.cnt->walked, (unsigned long long)n);
 		a.cnt->n_ray[ray_queue_index(par ^ 1, 0, 0) + threadIdx.x] = 0;
 	}
-	if (threadIdx.x < kShards)
-		a.cnt->head[(uint32_t)(par ^ 1) * kShards + threadIdx.x] = 0;
+	if (threadIdx.x < 2 * kShards)
+		a.cnt->head[(uint32_t)(par ^ 1) * 2 * kShards + threadIdx.x] = 0;
 
 	if (threadIdx.x == 0)
 		a.cnt->n_shadow = 0;
@@ -591,9 +593,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 		return;
 	if (PART == 2 && blockIdx.x < n_pulling)
 		return;
-	if (blockIdx.x < n_pulling) {
-		const uint32_t shard = blockIdx.x % kShards, part = blockIdx.x / kShards;
-		const uint32_t q = ray_queue_index(par, kBounceRays, shard);
+	// with camera_walk the camera rays' workgroups pull them through the walk as the bounce rays' do
+	const bool camera_pulls = WIDE && a.camera_walk && blockIdx.x >= n_pulling;
+	if (blockIdx.x < n_pulling || camera_pulls) {
+		const uint32_t block = camera_pulls ? blockIdx.x - n_pulling : blockIdx.x;
+		const int kind = camera_pulls ? kCameraRays : kBounceRays;
+		const uint32_t shard = block % kShards, part = block / kShards;
+		const uint32_t q = ray_queue_index(par, kind, shard);
 		const uint32_t total = a.cnt->n_ray[q];
 		// a short list is spread over up to 8 workgroups rather than worked through by
 		// one: towards the end of a render the steps are as long as their longest wave
@@ -601,15 +607,25 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 		const uint32_t rays_per_lane = spread < a.rays_per_lane ? (spread ? spread : 1u) : a.rays_per_lane;
 		if (part < pulling_blocks(total, rays_per_lane)) {
 			const float4 *queue = a.q_bounce + 2 * ((size_t)par * kShards + shard) * a.shard_cap;
+			uint32_t *head = &a.cnt->head[((uint32_t)par * kShards + shard) * 2 + (camera_pulls ? 1u : 0u)];
 			if (WIDE) {
 				WideCensus census = {0, 0, 0, 0, 0};
 				const uint32_t qd = ray_queue_index(par, kDoubtRays, shard);
 				traverse_wide_pulling<COUNT>(
 				    a.tree, kWideRefillAt, kWideQuorum, kWideWaiting, lds_stack + threadIdx.x, (int)a.wide_cap, wc, census,
-				    SharedList{total, &a.cnt->head[(uint32_t)par * kShards + shard], 32u * rays_per_lane},
-				    [&](uint32_t i, Ray &ray) {
+				    SharedList{total, head, 32u * rays_per_lane},
+				    [&](uint32_t i, Ray &ray, int32_t &hint) {
+					    if (camera_pulls) {
+						    // camera rays are queued by slot number only
+						    const uint32_t slot = a.q_ray[(size_t)q * a.shard_cap + i];
+						    const float4 r0 = a.ray0[slot], r1 = a.ray1[slot];
+						    ray = Ray{mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y)};
+						    hint = a.hint ? a.hint[slot] : -1;
+						    return slot;
+					    }
 					    const float4 r0 = queue[2 * (size_t)i], r1 = queue[2 * (size_t)i + 1];
 					    ray = Ray{mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y)};
+					    hint = -1;
 					    return __float_as_uint(r1.z);
 				    },
 				    [&](bool finished, uint32_t slot, const HitRec &h, bool doubt) {
@@ -626,7 +642,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 			} else
 			traverse_pulling<false, COUNT, true>(
 			    a.tree, a.refill_at, lds_stack + threadIdx.x, depth, wc,
-			    SharedList{total, &a.cnt->head[(uint32_t)par * kShards + shard], 32u * rays_per_lane},
+			    SharedList{total, head, 32u * rays_per_lane},
 			    [&](uint32_t i, Ray &ray, float &limit) {
 				    const float4 r0 = queue[2 * (size_t)i], r1 = queue[2 * (size_t)i + 1];
 				    ray = Ray{mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y)};
@@ -1071,6 +1087,8 @@ __global__ __launch_bounds__(kBlock) void k_init_slots(const RenderArgs a, uint3
 	if (i >= n_slots)
 		return;
 	a.ray1[i] = make_float4(0.f, 0.f, 1.f, __uint_as_float(kWaiting));
+	if (a.hint)
+		a.hint[i] = -1;
 }
 
 // ------------------------------------------------------------------ ray batches
@@ -1131,10 +1149,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 	traverse_wide_pulling<false>(
 	    tree, kBatchWalkRefillAt, kBatchWalkQuorum, kBatchWalkWaiting, lds_stack + threadIdx.x, cap, wc, cs,
 	    OwnChunk{(uint32_t)(n - begin < per_wave ? n - begin : per_wave), 0u},
-	    [&](uint32_t i, Ray &ray) {
+	    [&](uint32_t i, Ray &ray, int32_t &hint) {
 		    const uint32_t number = which ? which[i] : (uint32_t)begin + i;
 		    const float *r = rays + (size_t)number * 6;
 		    ray = Ray{mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5])};
+		    hint = -1;
 		    return number;
 	    },
 	    [&](bool finished, uint32_t number, const HitRec &h, bool doubt) {

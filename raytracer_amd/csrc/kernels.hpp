@@ -25,7 +25,7 @@ struct Counters {
 	// closest-hit queue lengths, [step parity][shard][kind]: the camera and the bounce counter of a
 	// shard are the halves of one aligned 64-bit word, which k_advance bumps with a single atomic
 	alignas(8) uint32_t n_ray[2 * kRayKinds * kShards];
-	uint32_t head[2 * kShards];                  // bounce-ray entries already drawn by traversal waves, [step parity][shard]
+	uint32_t head[2 * kShards * 2];              // queue entries already drawn by traversal waves, [step parity][shard][bounce, camera]
 	unsigned long long inner, tri, sph;     // RTA_RENDER_COUNT_WORK only
 	unsigned long long early;               // closest-hit queries answered where the ray was generated
 	unsigned long long retraced;            // closest-hit queries that the certified walk left to the exact traversal
@@ -86,6 +86,8 @@ struct RenderArgs {
 	                               // size, <= shard_cap, and at least the number of slots that can still queue a ray
 	uint32_t rays_per_lane, refill_at;     // bounce-ray traversal: see traverse_pulling
 	uint32_t leafwise;             // the tree has long leaves: traverse_leafwise, one ray per lane (rays_per_lane = 1)
+	uint32_t camera_walk;          // camera rays take the certified walk too (the camera lies within the wide tree's reach)
+	int32_t *hint;                 //   and start with the triangle the slot's last camera ray hit, [slot]; -1: none
 	uint32_t wide_cap;             // > 0: bounce rays take the certified walk over the wide tree, with this many LDS entries per lane
 	// occlusion queue, 3 per entry: (origin, limit) (direction, slot) (radiance, -)
 	float4 *shadow;

@@ -124,6 +124,17 @@ struct WideTraversal {
 		return __float_as_uint(t) & dmask;
 	}
 
+	// A triangle the ray is likely to hit (what the last ray through the same pixel hit, say), listed
+	// before the walk begins: tested first, it bounds the walk from its first node on.  Any triangle
+	// may be tested at any time, so the proof does not care where the hint comes from.
+	RTA_DEV void take_hint(uint32_t *stack, const int32_t hint)
+	{
+		if (hint >= 0 && !doubt) {
+			lp--;
+			stack[lp * STRIDE] = kWideLeaf | (uint32_t)hint;
+		}
+	}
+
 	RTA_DEV bool busy(const int cap) const { return node != kWideNone || sp > 0 || lp < cap; }
 	RTA_DEV bool has_node() const { return node != kWideNone || sp > 0; }
 	RTA_DEV bool has_list(const int cap) const { return lp < cap; }
@@ -247,8 +258,10 @@ struct WideTraversal {
 			if ((e & dmask) > reach)
 				return;
 		}
-		if (COUNT) work.tri++;
 		const uint32_t i = e & tree.wide_index_mask;
+		if ((int32_t)i == prim)
+			return;               // the hinted triangle, met again in the tree: no tie with itself
+		if (COUNT) work.tri++;
 		const float4 *rec = tree.prims + kPrimQuads * (size_t)i;
 		const float4 p0 = rec[0], p1 = rec[1], p2 = rec[2];
 		float tu = 0, tv = 0;
@@ -290,7 +303,8 @@ struct WideTraversal {
 
 // A wave works through more rays than it has lanes (as traverse_pulling).
 //   got = grab(want, first)                  reserves up to `want` rays
-//   tag = load(i, ray)                       fetches ray number i (ANY: load(i, ray, limit))
+//   tag = load(i, ray, hint)                 fetches ray number i and a triangle to test first, or -1
+//                                            (ANY: load(i, ray, limit))
 //   store(finished, tag, hit, doubt)         called by ALL lanes of the wave together; `finished` lanes
 //                                            hand in their ray's result, or `doubt`: trace it exactly
 // `quorum`: lanes with a listed triangle that make the wave run the triangle test; `waiting_quorum`: lanes
@@ -329,8 +343,10 @@ RTA_DEV void traverse_wide_pulling_as(const DeviceTree &tree, const uint32_t ref
 					tag = load(first + rank, ray, limit);
 					tr.start(tree, ray, cap, limit);
 				} else {
-					tag = load(first + rank, ray);
+					int32_t hint;
+					tag = load(first + rank, ray, hint);
 					tr.start(tree, ray, cap);
+					tr.take_hint(stack, hint);
 				}
 				loaded = true;
 			}

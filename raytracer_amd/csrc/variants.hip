@@ -328,9 +328,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 		traverse_wide_pulling<COUNT>(
 		    tree, refill_at, quorum, waiting_quorum, lds_stack + threadIdx.x, cap, wc, cs,
 		    SharedList{(uint32_t)(hi - lo), heads + shard, chunk},
-		    [&](uint32_t i, Ray &ray) {
+		    [&](uint32_t i, Ray &ray, int32_t &hint) {
 			    const float *r = mine + (size_t)i * 6;
 			    ray = Ray{mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5])};
+			    hint = -1;
 			    return i;
 		    },
 		    [&](bool finished, uint32_t i, const HitRec &h, bool doubt) {
@@ -344,9 +345,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 		traverse_wide_pulling<COUNT>(
 		    tree, refill_at, quorum, waiting_quorum, lds_stack + threadIdx.x, cap, wc, cs,
 		    OwnChunk{(uint32_t)(n - begin < per_wave ? n - begin : per_wave), 0u},
-		    [&](uint32_t i, Ray &ray) {
+		    [&](uint32_t i, Ray &ray, int32_t &hint) {
 			    const float *r = mine + (size_t)i * 6;
 			    ray = Ray{mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5])};
+			    hint = -1;
 			    return i;
 		    },
 		    [&](bool finished, uint32_t i, const HitRec &h, bool doubt) {

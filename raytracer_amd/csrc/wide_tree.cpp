@@ -29,6 +29,7 @@
 #include "wide_tree.hpp"
 
 #include <algorithm>
+#include <iterator>
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
@@ -374,7 +375,7 @@ WideTree build_wide_tree(const rta_scene_desc &d, bool tame)
 
 	// The admitted rays: the padding grows with the distance of the farthest admitted origin, so the
 	// wider reach (rays from outside the scene, a camera's say) is taken only where the boxes stay tight.
-	std::vector<double> candidates = {kWideReachRadiiFar, kWideReachRadii};
+	std::vector<double> candidates(std::begin(kWideReachRadii), std::end(kWideReachRadii));
 	if (getenv("RTA_WIDE_REACH"))
 		candidates = {atof(getenv("RTA_WIDE_REACH"))};
 	for (size_t trial = 0; trial < candidates.size(); trial++) {

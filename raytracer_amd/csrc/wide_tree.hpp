@@ -35,12 +35,11 @@ struct WideTree {
 	double mean_pad_over_extent = 0;  // diagnostic: padding relative to the padded child boxes' mean extent
 };
 
-// reach + scene radius, in scene radii: rays that start inside the sphere around the scene's box (bounce
-// rays do) are admitted; the padding grows with this number
-constexpr float kWideReachRadii = 2.05f;
-// the same for rays that start outside (a camera's, a batch's): taken when the padding it costs stays below
-// kWideMaxPadding of the boxes' extents (binary16 rounding of the planes included)
-constexpr float kWideReachRadiiFar = 4.f;
+// Reach + scene radius, in scene radii.  Rays that start within the reach are admitted; the padding grows
+// with it.  The smallest covers the sphere around the scene's box (bounce rays start there); the builder
+// takes the widest of these (rays from outside: a camera's, a batch's) whose padding stays below
+// kWideMaxPadding of the boxes' extents, binary16 rounding of the planes included.
+constexpr double kWideReachRadii[] = {4.0, 3.0, 2.5, 2.25, 2.05};
 constexpr double kWideMaxPadding = 0.03;
 
 // primitives up to which the wide tree gets a surface-area-heuristic topology of its own (a host-side build,

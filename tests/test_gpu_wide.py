@@ -184,7 +184,9 @@ def test_render_with_and_without_the_wide_tree(gpu):
     # the walk answers all but a sliver of the bounce rays itself
     bounce = st_a["rays"] - st_a["samples"]
     assert bounce > 100000 and st_a["retraced_rays"] < bounce // 1000
-    assert bounce * 0.99 <= st_a["walked_rays"] <= bounce      # all but the rays that need the division-based box test
+    # all bounce rays but those that need the division-based box test, and the camera rays where the camera is in reach
+    assert bounce * 0.99 <= st_a["walked_rays"] <= st_a["rays"] - st_a["early_rays"]
+    assert st_a["walked_rays"] > bounce      # dragon.txt's camera is: its rays walk too, each hinted at the slot's last hit
 
 
 def test_scenes_without_a_wide_tree_render_as_before(gpu):

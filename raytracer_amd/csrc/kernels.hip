@@ -61,9 +61,6 @@ constexpr float kNoSampleReaches = 0x1p-25f;
 // prove its answer (traverse_wide.hpp), queued by the traversal kernel itself for
 // the exact traversal that follows it
 constexpr int kCameraRays = 0, kBounceRays = 1, kOddRays = 2, kDoubtRays = 3;
-// certified walk: idle lanes that make a wave draw new rays, lanes with a listed triangle
-// (lanes with nothing else to do) that make it run the triangle test
-constexpr uint32_t kWideRefillAt = 16, kWideQuorum = 24, kWideWaiting = 16;
 
 RTA_DEV float4 f4(V3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
 RTA_DEV float4 f4u(V3 v, uint32_t w) { return make_float4(v.x, v.y, v.z, __uint_as_float(w)); }
@@ -612,7 +609,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 				WideCensus census = {0, 0, 0, 0, 0};
 				const uint32_t qd = ray_queue_index(par, kDoubtRays, shard);
 				traverse_wide_pulling<COUNT>(
-				    a.tree, kWideRefillAt, kWideQuorum, kWideWaiting, lds_stack + threadIdx.x, (int)a.wide_cap, wc, census,
+				    a.tree, a.walk_refill_at, a.walk_quorum, a.walk_waiting, lds_stack + threadIdx.x, (int)a.wide_cap, wc, census,
 				    SharedList{total, head, 32u * rays_per_lane},
 				    [&](uint32_t i, Ray &ray, int32_t &hint) {
 					    if (camera_pulls) {

@@ -86,6 +86,7 @@ struct RenderArgs {
 	                               // size, <= shard_cap, and at least the number of slots that can still queue a ray
 	uint32_t rays_per_lane, refill_at;     // bounce-ray traversal: see traverse_pulling
 	uint32_t leafwise;             // the tree has long leaves: traverse_leafwise, one ray per lane (rays_per_lane = 1)
+	uint32_t walk_refill_at, walk_quorum, walk_waiting;      // traverse_wide_pulling's thresholds for the render's rays
 	uint32_t camera_walk;          // camera rays take the certified walk too (the camera lies within the wide tree's reach)
 	int32_t *hint;                 //   and start with the triangle the slot's last camera ray hit, [slot]; -1: none
 	uint32_t wide_cap;             // > 0: bounce rays take the certified walk over the wide tree, with this many LDS entries per lane

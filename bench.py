@@ -307,7 +307,8 @@ def main():
             "traced_fraction": main_run["traced"] / main_run["queries"],
             "retraced_rays_per_step": main_run["retraced"] / args.steps,
             "walked_rays_per_step": main_run["walked"] / args.steps,
-            "traversal": ("certified walk over the wide tree for bounce rays, order-replaying traversal for the rest"
+            "traversal": ("certified walk over the wide tree (bounce and shadow rays; camera rays where the camera lies within "
+                          "the tree's reach), order-replaying traversal for the rest"
                           if main_run["walked"] else "order-replaying traversal (no wide tree for this scene, or --exact-only)"),
             "samples_per_s": m["samples_per_s"],
             "n_gpus": world,

@@ -485,6 +485,8 @@ WideTree build_wide_tree(const rta_scene_desc &d, bool tame)
 		if (w.mean_pad_over_extent <= kWideMaxPadding)
 			break;
 	}
+	if (w.mean_pad_over_extent > kWideHopelessPadding)
+		return refuse("triangles too large for the padding the walk needs");
 	w.enabled = true;
 	return w;
 }

@@ -41,6 +41,10 @@ struct WideTree {
 // kWideMaxPadding of the boxes' extents, binary16 rounding of the planes included.
 constexpr double kWideReachRadii[] = {4.0, 3.0, 2.5, 2.25, 2.05};
 constexpr double kWideMaxPadding = 0.03;
+// The padding grows with the square of a triangle's longest edge (the reference's determinant threshold is
+// absolute): a scene of large triangles would get boxes that all overlap.  Beyond this mean padding at the
+// smallest reach the scene gets no wide tree.
+constexpr double kWideHopelessPadding = 0.25;
 
 // primitives up to which the wide tree gets a surface-area-heuristic topology of its own (a host-side build,
 // O(n log n)); beyond, it keeps the reference tree's

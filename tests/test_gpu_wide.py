@@ -219,3 +219,19 @@ def test_shadow_rays_take_the_any_hit_walk(gpu):
         assert st["rays"] == cn["rays"] and st["shadow_rays"] == cn["shadow_rays"] and st["shadow_rays"] > 10000
         assert np.array_equal(bits(acc), bits(want_acc)) and np.array_equal(bgr, want_bgr)
         assert (st["walked_rays"] > 0) == (flags == 0)
+
+
+def test_large_triangles_get_no_wide_tree(gpu):
+    """The walk's padding grows with the square of the triangles' edges: a room of twelve big triangles keeps the
+    replaying traversal, and renders as the checker does."""
+    c = [(x, y, z) for x in (0.0, 2.0) for y in (0.0, 2.0) for z in (0.0, 2.0)]
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    tris = np.float32([c[q[0]] + c[q[1]] + c[q[2]] for q in quads] + [c[q[0]] + c[q[2]] + c[q[3]] for q in quads])
+    text = _mesh_scene(tris).replace("camera [0.5 0.5 3]", "camera [1 1 1]").replace("look_at [0.5 0.5 0]", "look_at [1.9 1.2 0.3]")
+    osc = orc.Scene.parse(text).build_bvh()
+    psc = rta.Scene.parse(text).build_bvh()
+    gpu.upload(psc)
+    want_bgr, want_acc, cn = osc.render(orc.RNG_STREAM, orc.MATH_PM, seed=2, samples_per_stream=4)
+    bgr, acc, st = gpu.render_scene(psc, seed=2, samples_per_stream=4)
+    assert st["walked_rays"] == 0 and st["rays"] == cn["rays"] > 2 * cn["samples"]
+    assert np.array_equal(bits(acc), bits(want_acc)) and np.array_equal(bgr, want_bgr)

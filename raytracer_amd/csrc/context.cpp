@@ -131,6 +131,8 @@ TreeRef tree_of(const rta_context *ctx)
 	memcpy(t.wide_center, ctx->wide_center, 12);
 	t.wide_reach2 = ctx->wide_reach2;
 	t.wide_index_mask = ctx->wide_index_mask;
+	t.n_loose = ctx->have_wide ? ctx->n_loose : 0u;
+	t.loose = ctx->loose.as<const uint32_t>();
 	t.wide_index_bits = (uint32_t)__builtin_popcount(ctx->wide_index_mask);
 	// with fewer than 11 bits left for the distance, a float's leading bits say too little
 	static const char *relative = getenv("RTA_WIDE_RELATIVE");      // measurement
@@ -450,6 +452,9 @@ int rta_upload_scene(rta_context *ctx, const rta_scene_desc *desc)
 		ctx->wide_depth = wide.depth;
 		ctx->wide_index_mask = wide.index_mask;
 		ctx->wide_span = wide.span;
+		ctx->n_loose = (uint32_t)wide.spheres.size();
+		if (!wide.spheres.empty() && (rc = upload_vec(ctx, ctx->loose, wide.spheres)))
+			return rc;
 	}
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // the staging vectors die with this call
 	ctx->have_wide = wide.enabled;

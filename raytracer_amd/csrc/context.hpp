@@ -60,6 +60,8 @@ struct rta_context {
 	int wide_depth = 0;
 	uint32_t wide_index_mask = 0;
 	float wide_span = 1;
+	uint32_t n_loose = 0;                     // the wide tree's spheres
+	rta::DeviceBuffer loose;
 	rta::DeviceBuffer soa_nodes;      // variant 5 only, made from `pairs` on first use
 	uint32_t n_pairs = 0;
 	bool have_soa = false;

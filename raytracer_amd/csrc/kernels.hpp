@@ -48,6 +48,8 @@ struct TreeRef {
 	uint32_t wide_index_bits;    //   and that number of bits
 	uint32_t wide_relative;      // distance bits of the entries count from the ray's entry into the scene's box (big scenes)
 	uint32_t wide_key_base;      //   and are the bits of the float distance above this pattern (WideTraversal::distance_bits)
+	uint32_t n_loose;            // spheres, which the walk tests one by one for every ray:
+	const uint32_t *loose;       //   their primitive numbers
 };
 
 constexpr uint32_t kWideLeaf = 0x80000000u;     // child reference of a wide node: kWideLeaf | primitive,

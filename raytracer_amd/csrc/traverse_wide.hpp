@@ -96,6 +96,26 @@ struct WideTraversal {
 		    ray_is_tame(r) && norm2(r.d) <= kWideMaxDir * kWideMaxDir * (1.f - 0x1p-20f) && norm2(from) <= tree.wide_reach2;
 		doubt = !admitted;
 		node = admitted ? 0u : kWideNone;
+		// Spheres are outside the tree: each is tested here, with the reference's own arithmetic, before the
+		// walk begins (step 1 of the proof holds for them trivially: every one is tested).
+		if (admitted)
+			for (uint32_t k = 0; k < tree.n_loose; k++) {
+				const uint32_t i = tree.loose[k];
+				const float4 *rec = tree.prims + kPrimQuads * (size_t)i;
+				const float4 p0 = rec[0], p1 = rec[1];
+				const float t = test_sphere(mk(p0.x, p0.y, p0.z), p1.x, r);
+				if (t < best) {
+					prim = (int32_t)i;
+					if (ANY) {
+						node = kWideNone;      // an occluder: nothing left to walk
+					} else {
+						best = t;
+						tie = false;
+					}
+				} else if (!ANY && t == best && t < FLT_MAX) {
+					tie = true;
+				}
+			}
 		t_enter = 0.f;
 		if (REL) {
 			// (an estimate is enough: distance_bits() is monotonic whatever t_enter is)

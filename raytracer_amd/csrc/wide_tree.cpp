@@ -322,14 +322,19 @@ WideTree build_wide_tree(const rta_scene_desc &d, bool tame)
 			const float *nb = d.node_bounds + (size_t)node * 6;
 			if (cnt > 0) {
 				for (int32_t p = idx; p < idx + cnt; p++) {
-					if (d.prim_type[p] != RTA_PRIM_TRIANGLE)
-						return refuse("the scene has spheres");
 					const float *g = d.prim_geom + (size_t)p * 9;
+					w.leaf_boxes[(size_t)p * 2] = make_float4(nb[0], nb[1], nb[2], 0);
+					w.leaf_boxes[(size_t)p * 2 + 1] = make_float4(nb[3], nb[4], nb[5], 0);
+					if (d.prim_type[p] != RTA_PRIM_TRIANGLE) {
+						// a few spheres stay outside the tree and are tested for every ray
+						if (w.spheres.size() == kWideMaxSpheres)
+							return refuse("more spheres than the walk tests one by one");
+						w.spheres.push_back(p);
+						continue;
+					}
 					for (int k = 0; k < 9; k++)
 						if (!std::isfinite(g[k]))
 							return refuse("non-finite vertex");
-					w.leaf_boxes[(size_t)p * 2] = make_float4(nb[0], nb[1], nb[2], 0);
-					w.leaf_boxes[(size_t)p * 2 + 1] = make_float4(nb[3], nb[4], nb[5], 0);
 					covered.push_back(p);
 				}
 				continue;
@@ -345,13 +350,18 @@ WideTree build_wide_tree(const rta_scene_desc &d, bool tame)
 		}
 	}
 
+	if (covered.size() < 2)
+		return refuse("fewer than two triangles");
+
 	Builder bu(d);
 	bu.b.reserve((size_t)d.n_prims * 2);
 	// Topology: by surface-area heuristic where the build stays short, else the reference's own.  (Both
 	// put every covered primitive in exactly one leaf; the reference's tree always supplies the leaf
 	// boxes of step 3 of the proof.)
 	int32_t root;
-	if (covered.size() <= kWideSahLimit && !getenv("RTA_WIDE_MIDPOINT")) {
+	if (!w.spheres.empty() && covered.size() > kWideSahLimit)
+		return refuse("spheres in a scene beyond the size of the heuristic build");      // (the reference's leaves mix both kinds)
+	if (covered.size() <= kWideSahLimit && (!getenv("RTA_WIDE_MIDPOINT") || !w.spheres.empty())) {
 		bu.ids = covered;
 		root = bu.sah(0, (int32_t)covered.size());
 	} else {

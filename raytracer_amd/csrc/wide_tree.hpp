@@ -26,6 +26,8 @@ struct WideTree {
 	std::vector<float4> nodes;
 	// 2 x 16 bytes per primitive: the box of its leaf in the reference's tree (lo, hi)
 	std::vector<float4> leaf_boxes;
+	// spheres are not in the tree: the walk tests each of them for every ray (at most kWideMaxSpheres)
+	std::vector<int32_t> spheres;
 	float center[3] = {0, 0, 0};      // rays may take the wide tree when |origin - center| <= reach
 	float reach = 0;                  //   and |direction| <= kWideMaxDir
 	float span = 0;                   // >= reach + the radius of the scene's sphere: no admitted ray of unit direction is in the scene beyond
@@ -45,6 +47,9 @@ constexpr double kWideMaxPadding = 0.03;
 // absolute): a scene of large triangles would get boxes that all overlap.  Beyond this mean padding at the
 // smallest reach the scene gets no wide tree.
 constexpr double kWideHopelessPadding = 0.25;
+
+// spheres a scene may have and still get a wide tree over its triangles
+constexpr size_t kWideMaxSpheres = 8;
 
 // primitives up to which the wide tree gets a surface-area-heuristic topology of its own (a host-side build,
 // O(n log n)); beyond, it keeps the reference tree's

@@ -189,8 +189,49 @@ def test_render_with_and_without_the_wide_tree(gpu):
     assert st_a["walked_rays"] > bounce      # dragon.txt's camera is: its rays walk too, each hinted at the slot's last hit
 
 
+def test_a_few_spheres_beside_the_mesh(gpu):
+    """Spheres stay outside the wide tree and are tested for every ray: a bumpy grid with a sphere above it, one cutting
+    through it and a light; batches, occlusion queries and the render against the checker."""
+    tris = _grid_mesh(20, lambda x, y: 0.1 * np.sin(9 * x) * np.cos(7 * y))
+    body = " ".join("%r" % float(x) for x in tris.reshape(-1))
+    text = ("render {\n\tcamera [0.5 0.5 2.2]\n\tlook_at [0.5 0.5 0]\n\tup [0 1 0]\n\twidth 56\n\theight 40\n\tsamples 16\n\tfov 30\n"
+            "\tsky_box_color [.3 .4 .6]\n}\n\nmaterial {\n\tcolor [0.8 0.7 0.6]\n\troughness 0.4\n\tmetallic 1\n}\n\n"
+            "sphere {\n\tcenter [0.3 0.6 0.35]\n\tradius 0.15\n}\n\nsphere {\n\tcenter [0.7 0.4 0.02]\n\tradius 0.12\n}\n\n"
+            "material {\n\tcolor [0.7 0.8 0.6]\n\troughness 1\n}\n\ntriangle_mesh {\n\tvertices [ %s ]\n}\n\n"
+            "material {\n\tcolor [0 0 0]\n\troughness 1\n}\n\narea_light {\n\tcolor [9 9 8]\n}\n\n"
+            "triangle_mesh {\n\tvertices [ 0.4 0.4 1.0  0.6 0.4 1.0  0.5 0.6 1.05 ]\n}\n" % body)
+    osc = orc.Scene.parse(text).build_bvh()
+    psc = rta.Scene.parse(text).build_bvh()
+    gpu.upload(psc)
+    nodes = osc.nodes()
+    lo, hi = nodes["lo"][0], nodes["hi"][0]
+    rng = np.random.default_rng(17)
+    rr = raygen.random_rays(200000, lo - 0.2, hi + 0.2, seed=9)
+    # half of them aimed at the spheres
+    for c, r in (((0.3, 0.6, 0.35), 0.15), ((0.7, 0.4, 0.02), 0.12)):
+        sel = rng.random(rr.shape[0]) < 0.25
+        target = np.float32(c) + rng.standard_normal((int(sel.sum()), 3)).astype(np.float32) * np.float32(r * 0.6)
+        d = target - rr[sel, 0:3]
+        rr[sel, 3:6] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    idx, t, u, v = osc.trace_closest(rr)
+    want = dict(prim=idx, t=t, u=u, v=v)
+    for got in (walk(gpu, rr), batch(gpu, rr)):
+        ok = same_hits(got, want)
+        assert ok.all(), f"{(~ok).sum()} rays differ, first {rr[np.nonzero(~ok)[0][0]].tolist()}"
+    types = psc.arrays()["prim_type"]
+    assert (types[idx[idx >= 0]] != 0).sum() > 5000      # spheres are among the answers
+    k = rng.integers(0, 5, rr.shape[0])
+    with np.errstate(over="ignore"):
+        limit = np.where(idx >= 0, t * np.float32([0.6, 0.9999999, 1.0, 1.0000001, 1.7])[k], np.float32(3.0)).astype(np.float32)
+    assert np.array_equal(gpu.trace_occluded(rr, limit), osc.trace_occluded(rr, limit))
+    want_bgr, want_acc, cn = osc.render(orc.RNG_STREAM, orc.MATH_PM, seed=8, samples_per_stream=4)
+    bgr, acc, st = gpu.render_scene(psc, seed=8, samples_per_stream=4)
+    assert st["rays"] == cn["rays"] and st["shadow_rays"] == cn["shadow_rays"] and st["walked_rays"] > 0
+    assert np.array_equal(bits(acc), bits(want_acc)) and np.array_equal(bgr, want_bgr)
+
+
 def test_scenes_without_a_wide_tree_render_as_before(gpu):
-    """Spheres keep a scene on the exact traversal (cornell_box.txt has one); variant 20 says so."""
+    """Large triangles keep a scene on the exact traversal (cornell_box.txt's walls); variant 20 says so."""
     psc = rta.Scene.load(f"{orc.SCENES}/cornell_box.txt").build_bvh()
     gpu.upload(psc)
     with pytest.raises(rta.RtaError):

@@ -853,7 +853,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	base.sps = sps;
 	base.width = (uint32_t)p->width;
 	base.seed = p->seed;
-	base.max_bounces = p->max_bounces > 0 ? p->max_bounces : 10;
+	base.max_bounces = p->max_bounces > 0 ? std::min(p->max_bounces, 1 << 20) : 10;      // (the slot state numbers bounces in 24 bits)
 	memcpy(base.sky, p->sky, sizeof base.sky);
 	base.cam = *camera;
 	Projection projection;

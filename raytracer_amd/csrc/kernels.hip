@@ -49,7 +49,10 @@ namespace rta {
 
 namespace {
 
-// slot states kept in the bounce word (ray1.w): a bounce number, or
+// slot states kept in the bounce word (ray1.w): a bounce number (with kHasColour: the path has gathered
+// radiance, or an occlusion query may add some, and col[slot] holds it; without, its radiance is 0 and
+// col[slot] is neither written nor read), or
+constexpr uint32_t kHasColour = 0x01000000u;
 constexpr uint32_t kWaiting = 0xfffffffdu;     // through with its blocks; waits for the wave's next tile
 constexpr uint32_t kRetired = 0xfffffffeu;     // no work left for this wave
 constexpr uint32_t kEnded = 0xffffffffu;       // path finished, its occlusion query pending; retired by the next pass
@@ -117,7 +120,8 @@ RTA_DEV void ray_queues_push(const RenderArgs &a, int par, bool camera, bool bou
 		}
 		if (bounce && tame) {
 			const uint32_t at = base_b + __builtin_amdgcn_mbcnt_hi((uint32_t)(bnc >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bnc, 0u));
-			a.q_ray[(size_t)qb * a.shard_cap + at] = slot;
+			if (a.leafwise)      // (the other traversal kernels find the slot number in the entry below)
+				a.q_ray[(size_t)qb * a.shard_cap + at] = slot;
 			float4 *e = a.q_bounce + 2 * (((size_t)par * kShards + shard) * a.shard_cap + at);
 			e[0] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.d.x);
 			e[1] = make_float4(ray.d.y, ray.d.z, __uint_as_float(slot), 0.f);
@@ -233,13 +237,14 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 	uint32_t rng = 0;
 
 	if (state < kWaiting) {
-		const uint32_t bounce = state;
+		const uint32_t bounce = state & (kHasColour - 1);
 		const float4 H = a.hit[slot];
 		rng = a.rng[slot];
 		V3 thr = mk(1, 1, 1);
 		if (bounce > 0) {
 			thr = xyz(a.thr[slot]);
-			color = xyz(a.col[slot]);
+			if (state & kHasColour)
+				color = xyz(a.col[slot]);
 		}
 		const int32_t prim = __float_as_int(H.x);
 
@@ -344,8 +349,10 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 			}
 			if (!stop && bounce + 1 < (uint32_t)a.max_bounces) {
 				const V3 nd = to_world(fr, bs.l);
+				// (with lights nearly every path gathers at once: not worth the test)
+				const bool gathered = a.n_lights > 0 || ((__float_as_uint(color.x) | __float_as_uint(color.y) | __float_as_uint(color.z)) != 0);
 				a.ray0[slot] = make_float4(point.x, point.y, point.z, nd.x);
-				a.ray1[slot] = make_float4(nd.y, nd.z, bs.pdf, __uint_as_float(bounce + 1));
+				a.ray1[slot] = make_float4(nd.y, nd.z, bs.pdf, __uint_as_float((bounce + 1) | (gathered ? kHasColour : 0u)));
 				a.thr[slot] = f4(thr, 0.f);
 				next_ray = Ray{point, nd};
 				alive = true;
@@ -353,8 +360,9 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 		}
 		if (alive || want_shadow) {
 			// the radiance so far is needed again: by the next bounce, or by the
-			// occlusion query that may add the light's share to it
-			a.col[slot] = f4(color, 0.f);
+			// occlusion query that may add the light's share to it (nothing to keep while it is 0)
+			if (a.n_lights > 0 || ((__float_as_uint(color.x) | __float_as_uint(color.y) | __float_as_uint(color.z)) != 0))
+				a.col[slot] = f4(color, 0.f);
 			if (!alive)
 				state = kEnded;         // retired by the next pass, after k_shadow has run
 			a.rng[slot] = rng;

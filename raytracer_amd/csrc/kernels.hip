@@ -97,6 +97,19 @@ RTA_DEV void count_flush(Counters *cnt, const WorkCount &wc)
 // lengths in Counters::n_ray in the same order.
 RTA_DEV uint32_t ray_queue_index(int par, int kind, uint32_t shard) { return ((uint32_t)par * kShards + shard) * kRayKinds + (uint32_t)kind; }
 
+// The ray a slot holds: ray1 = (direction, bounce word), ray0 = (origin, pdf of the direction).  A pinhole
+// camera's rays (bounce word 0) all start at the pinhole with pdf 1: their ray0 is neither written nor read.
+RTA_DEV bool pinhole(const RenderArgs &a) { return !(a.cam.defocus_angle > 0); }
+
+RTA_DEV Ray slot_ray(const RenderArgs &a, uint32_t slot)
+{
+	const float4 r1 = a.ray1[slot];
+	V3 o = mk(a.cam.origin[0], a.cam.origin[1], a.cam.origin[2]);
+	if (!pinhole(a) || __float_as_uint(r1.w) != 0u)
+		o = xyz(a.ray0[slot]);
+	return Ray{o, xyz(r1)};
+}
+
 // A wave's camera rays (lanes with `camera`) and bounce rays (lanes with `bounce`; no lane has
 // both) join their queues with ONE atomic on the shard's 64-bit pair of counters: an atomic that
 // returns a value is a round trip to the memory side that the wave sits out.  Must be reached by
@@ -252,9 +265,11 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 			// src/main.cpp:511-514
 			color = color + thr * mk(a.sky[0], a.sky[1], a.sky[2]);
 		} else {
-			const float4 r0 = a.ray0[slot];
-			const Ray ray = {mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y)};
-			const float prev_pdf = r1.z;
+			float4 r0 = make_float4(a.cam.origin[0], a.cam.origin[1], a.cam.origin[2], 1.f);
+			if (bounce > 0 || !pinhole(a))
+				r0 = a.ray0[slot];
+			const Ray ray = {xyz(r0), xyz(r1)};
+			const float prev_pdf = r0.w;
 			const float t = H.y, bu = H.z, bv = H.w;
 			const float4 s0 = a.shade_prims[3 * (size_t)prim];
 			const float4 s1 = a.shade_prims[3 * (size_t)prim + 1];
@@ -351,8 +366,8 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 				const V3 nd = to_world(fr, bs.l);
 				// (with lights nearly every path gathers at once: not worth the test)
 				const bool gathered = a.n_lights > 0 || ((__float_as_uint(color.x) | __float_as_uint(color.y) | __float_as_uint(color.z)) != 0);
-				a.ray0[slot] = make_float4(point.x, point.y, point.z, nd.x);
-				a.ray1[slot] = make_float4(nd.y, nd.z, bs.pdf, __uint_as_float((bounce + 1) | (gathered ? kHasColour : 0u)));
+				a.ray0[slot] = make_float4(point.x, point.y, point.z, bs.pdf);
+				a.ray1[slot] = make_float4(nd.x, nd.y, nd.z, __uint_as_float((bounce + 1) | (gathered ? kHasColour : 0u)));
 				a.thr[slot] = f4(thr, 0.f);
 				next_ray = Ray{point, nd};
 				alive = true;
@@ -524,8 +539,9 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 		a.rng[slot] = rng;
 		if (meta_changed)
 			a.meta[slot] = M;
-		a.ray0[slot] = make_float4(next_ray.o.x, next_ray.o.y, next_ray.o.z, next_ray.d.x);
-		a.ray1[slot] = make_float4(next_ray.d.y, next_ray.d.z, 1.f, __uint_as_float(0u));     // bsdf_pdf = 1, bounce 0
+		if (!pinhole(a))
+			a.ray0[slot] = make_float4(next_ray.o.x, next_ray.o.y, next_ray.o.z, 1.f);     // bsdf_pdf = 1
+		a.ray1[slot] = make_float4(next_ray.d.x, next_ray.d.y, next_ray.d.z, __uint_as_float(0u));     // bounce 0
 	} else if (state >= kWaiting && state != __float_as_uint(r1.w)) {
 		a.ray1[slot] = make_float4(r1.x, r1.y, r1.z, __uint_as_float(state));
 	}
@@ -623,8 +639,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 					    if (camera_pulls) {
 						    // camera rays are queued by slot number only
 						    const uint32_t slot = a.q_ray[(size_t)q * a.shard_cap + i];
-						    const float4 r0 = a.ray0[slot], r1 = a.ray1[slot];
-						    ray = Ray{mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y)};
+						    ray = slot_ray(a, slot);
 						    hint = a.hint ? a.hint[slot] : -1;
 						    return slot;
 					    }
@@ -666,8 +681,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 		const uint32_t i = part * kBlock + threadIdx.x;
 		if (i < total) {
 			const uint32_t slot = a.q_ray[(size_t)q * a.shard_cap + i];
-			const float4 r0 = a.ray0[slot], r1 = a.ray1[slot];
-			Ray ray = {mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y)};
+			Ray ray = slot_ray(a, slot);
 			HitRec h;
 			traverse_dyn<false, COUNT, true>(a.tree, ray, FLT_MAX, lds_stack + threadIdx.x, depth, h, wc);
 			a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
@@ -697,8 +711,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 	WorkCount wc = {0, 0, 0};
 	if (i < total) {
 		const uint32_t slot = a.q_ray[(size_t)q * a.shard_cap + i];
-		const float4 r0 = a.ray0[slot], r1 = a.ray1[slot];
-		Ray ray = {mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y)};
+		Ray ray = slot_ray(a, slot);
 		HitRec h;
 		traverse_leafwise<false, COUNT, true>(a.tree, ray, FLT_MAX, lds_stack + threadIdx.x, depth, h, wc);
 		a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
@@ -724,8 +737,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect_odd(const RenderArgs a, co
 			atomicAdd(&a.cnt->retraced, (unsigned long long)total);
 		for (uint32_t i = part * kBlock + threadIdx.x; i < total; i += parts * kBlock) {
 			const uint32_t slot = a.q_ray[(size_t)q * a.shard_cap + i];
-			const float4 r0 = a.ray0[slot], r1 = a.ray1[slot];
-			Ray ray = {mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y)};
+			Ray ray = slot_ray(a, slot);
 			HitRec h;
 			traverse_dyn<false, COUNT, false>(a.tree, ray, FLT_MAX, lds_stack + threadIdx.x, depth, h, wc);
 			a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);

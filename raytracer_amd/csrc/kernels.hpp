@@ -69,8 +69,8 @@ struct RenderArgs {
 	int32_t n_lights;
 
 	// per path slot
-	float4 *ray0;                  // origin xyz, direction x
-	float4 *ray1;                  // direction yz, pdf of the sampled direction, bounce or slot state
+	float4 *ray0;                  // origin xyz, pdf of the sampled direction (not kept for a pinhole camera's rays)
+	float4 *ray1;                  // direction xyz, bounce word or slot state
 	float4 *hit;                   // primitive, t, u, v
 	float4 *thr;                   // throughput rgb (kept from the second segment of a path on)
 	float4 *col;                   // path radiance rgb (likewise)

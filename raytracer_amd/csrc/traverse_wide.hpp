@@ -171,11 +171,11 @@ struct WideTraversal {
 
 	// Precondition: node != kWideNone && has_room()
 	//
-	// A child's key is its reference (bit 31: triangle; 23 bits of node or primitive
-	// number) with 8 bits of the distance at which the ray enters its box in between,
-	// or all ones for a miss.  Sorted as unsigned numbers the four keys come out as
-	// nodes nearest first, then triangles nearest first, then misses, and the keys are
-	// at once the stack and list entries (see entry_lower_bound).
+	// A child's key is its reference (bit 31: triangle; below, as many bits of node or primitive
+	// number as the scene needs) with distance bits of the point where the ray enters its box in
+	// between (distance_bits), or all ones for a miss.  Sorted as unsigned numbers the four keys
+	// come out as nodes nearest first, then triangles nearest first, then misses, and the keys
+	// are at once the stack and list entries.
 	RTA_DEV void visit(const DeviceTree &tree, uint32_t *stack, WorkCount &work)
 	{
 		if (COUNT) work.inner++;

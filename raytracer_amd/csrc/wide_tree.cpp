@@ -1,10 +1,12 @@
 // Host-side builder of the 4-wide tree of the certified traversal.
 //
-// Topology: the reference's tree (src/main.cpp:170-248) with every leaf of more
-// than one primitive cut further (median of the centroids on the longest axis)
-// until each primitive has a box of its own, then collapsed: a wide node starts
-// with the two children of a binary node and replaces the inner child with the
-// largest surface by its two children until it has four or none is left to open.
+// Topology: a binary tree with one triangle per leaf - up to kWideSahLimit triangles built by
+// the surface-area heuristic (the walk's proof does not depend on the tree), beyond that the
+// reference's tree (src/main.cpp:170-248) with every leaf of more than one primitive cut further
+// (median of the centroids on the longest axis) - collapsed: a wide node starts with the two
+// children of a binary node and replaces the inner child with the largest surface by its two
+// children until it has four or none is left to open.  Spheres stay outside the tree
+// (WideTree::spheres); the reference's tree always supplies the leaf boxes that certify an answer.
 //
 // Boxes: the exact bounds of the primitives' vertices, widened by a padding P
 // that depends on the longest triangle edge E below the box.  The padding makes

@@ -823,7 +823,7 @@ RTA_DEV void occluded_by_walk(const DeviceTree &tree, uint32_t *stack, const int
 }
 
 // k_shadow for scenes with a wide tree: a wave takes 64 consecutive queue entries through the any-hit walk.
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_shadow_walk(const RenderArgs a, const int depth)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_shadow_walk(const RenderArgs a, const int depth)
 {
 	extern __shared__ uint32_t lds_stack[];
 	const uint32_t n = a.cnt->n_shadow;
@@ -1118,14 +1118,20 @@ constexpr uint32_t kBatchRefillAt = 16;
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_batch_closest(const DeviceTree tree, const float *rays, uint64_t n,
                                                           rta_hit *hits, const int depth, Counters *cnt,
-                                                          const uint32_t rays_per_lane, const uint32_t *order)
+                                                          const uint32_t rays_per_lane, const uint32_t *order,
+                                                          const uint32_t *count_from)
 {
 	extern __shared__ uint32_t lds_stack[];
+	// (a list whose length only the device knows: the rays a walk handed on; n is then its capacity)
+	if (count_from)
+		n = *count_from;
 	// wave w of the grid owns rays [w 64 kBatchRaysPerLane, (w + 1) 64 kBatchRaysPerLane)
 	const uint64_t per_wave = 64 * (uint64_t)rays_per_lane;
-	const uint64_t begin = ((uint64_t)blockIdx.x * (kBlock / 64) + threadIdx.x / 64) * per_wave;
+	const uint64_t first = ((uint64_t)blockIdx.x * (kBlock / 64) + threadIdx.x / 64) * per_wave;
+	// (with count_from the grid may be smaller than the list: its waves stride over it)
+	const uint64_t stride = (uint64_t)gridDim.x * (kBlock / 64) * per_wave;
 	WorkCount wc = {0, 0, 0};
-	if (begin < n) {
+	for (uint64_t begin = first; begin < n; begin += stride) {
 		// the wave's rays: numbers begin.. of the batch, or of the tracing order
 		const float *mine = order ? rays : rays + begin * 6;
 		rta_hit *out = order ? hits : hits + begin;
@@ -1151,7 +1157,8 @@ __global__ __launch_bounds__(kBlock) void k_batch_closest(const DeviceTree tree,
 // answer are listed in `doubts` (ray numbers, *n_doubts of them) for k_batch_closest to trace.
 constexpr uint32_t kBatchWalkRefillAt = 24, kBatchWalkQuorum = 24, kBatchWalkWaiting = 64;
 
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_batch_walk(
+// (seven waves per SIMD: at eight, 64 registers, the kernel spills ten of them in its loop)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_batch_walk(
     const DeviceTree tree, const float *rays, uint64_t n, rta_hit *hits, const int cap, const uint32_t rays_per_lane,
     const uint32_t *order, uint32_t *doubts, uint32_t *n_doubts)
 {
@@ -1218,7 +1225,7 @@ __global__ __launch_bounds__(kBlock) void k_batch_occluded(const DeviceTree tree
 }
 
 // k_batch_occluded by the any-hit walk over the wide tree.
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_batch_occluded_walk(
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_batch_occluded_walk(
     const DeviceTree tree, const float *rays, const float *tmax, uint64_t n, uint8_t *out, const int cap, const int depth,
     const uint32_t rays_per_lane, const uint32_t *order)
 {
@@ -1353,14 +1360,19 @@ void launch_resolve(hipStream_t s, const float *frame, const int32_t *pixels, ui
 }
 
 void launch_batch_closest(hipStream_t s, const TreeRef &tree, const float *rays, uint64_t n, rta_hit *hits, int depth,
-                          Counters *cnt, const uint32_t *order)
+                          Counters *cnt, const uint32_t *order, const uint32_t *count_from)
 {
 	if (cnt)
 		hipLaunchKernelGGL(k_batch_closest<true>, dim3(batch_blocks(n)), dim3(kBlock), stack_bytes(depth), s, tree, rays,
-		                   n, hits, depth, cnt, batch_rays_per_lane(n), order);
+		                   n, hits, depth, cnt, batch_rays_per_lane(n), order, count_from);
+	else if (count_from)
+		// one ray per lane and a grid for up to a 64th of the capacity (the list is short); workgroups beyond the
+		// list's end leave at once, and a longer list is worked through in strides
+		hipLaunchKernelGGL(k_batch_closest<false>, dim3(std::max(1u, blocks_for(n / 64))), dim3(kBlock), stack_bytes(depth), s,
+		                   tree, rays, n, hits, depth, cnt, 1u, order, count_from);
 	else
 		hipLaunchKernelGGL(k_batch_closest<false>, dim3(batch_blocks(n)), dim3(kBlock), stack_bytes(depth), s, tree,
-		                   rays, n, hits, depth, cnt, batch_rays_per_lane(n), order);
+		                   rays, n, hits, depth, cnt, batch_rays_per_lane(n), order, count_from);
 }
 
 void launch_batch_walk(hipStream_t s, const TreeRef &tree, const float *rays, uint64_t n, rta_hit *hits, int cap,

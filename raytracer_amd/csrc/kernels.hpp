@@ -153,9 +153,10 @@ void launch_sum_blocks(hipStream_t s, const float4 *partial, const int32_t *pixe
                        float *frame, bool resume);
 void launch_resolve(hipStream_t s, const float *frame, const int32_t *pixels, uint32_t n, float samples, float exposure,
                     uint8_t *bgr);
-// `order`: null, or the n ray numbers in the order in which they are to be traced (n < 2^32)
+// `order`: null, or the n ray numbers in the order in which they are to be traced (n < 2^32);
+// `count_from`: null, or where the device finds how many of the n entries of `order` are in use
 void launch_batch_closest(hipStream_t s, const TreeRef &tree, const float *rays, uint64_t n, rta_hit *hits, int depth,
-                          Counters *cnt, const uint32_t *order = nullptr);
+                          Counters *cnt, const uint32_t *order = nullptr, const uint32_t *count_from = nullptr);
 // the certified walk over the wide tree; rays left in doubt are listed for launch_batch_closest (order = doubts)
 void launch_batch_walk(hipStream_t s, const TreeRef &tree, const float *rays, uint64_t n, rta_hit *hits, int cap,
                        const uint32_t *order, uint32_t *doubts, uint32_t *n_doubts);

@@ -15,7 +15,8 @@
 // All calls on one GPU share that GPU's array, so two such calls that overlap
 // in time on one GPU race, also from different contexts.  The array keeps the
 // last call's contents; the only word that must start at zero (the count of
-// out-of-order keys that k_ray_keys adds to) is cleared by launch_ray_keys.
+// out-of-order keys that k_ray_keys adds to, later the count of rays that the
+// certified walk hands on) is cleared by launch_ray_keys and by launch_batch_walk.
 
 #include <hip/hip_runtime.h>
 
@@ -100,7 +101,15 @@ extern "C" int rta_trace_closest_static(rta_context *ctx, const float *rays, int
 		HIP_TRY(ctx, launch_ray_sort(ctx->stream, count, keys, keys_sorted, index, sorted, base + 4 * kEach, temp));
 		order = sorted;
 	}
-	launch_batch_closest(ctx->stream, tree_of(ctx), rays, (uint64_t)n, hits, ctx->stack_depth, nullptr, order);
+	if (ctx->have_wide && order) {
+		// The certified walk first (as rta_trace_closest): once the order is sorted, the keys' array is free to
+		// take the list of the rays that the walk hands on, and the word that counted the out-of-order keys
+		// their number (cleared by launch_batch_walk); the replaying traversal then runs over that list.
+		uint32_t *doubts = (uint32_t *)base, *n_doubts = (uint32_t *)(base + 4 * kEach + kTempBytes);
+		launch_batch_walk(ctx->stream, tree_of(ctx), rays, (uint64_t)n, hits, kBatchWalkCap, order, doubts, n_doubts);
+		launch_batch_closest(ctx->stream, tree_of(ctx), rays, (uint64_t)n, hits, ctx->stack_depth, nullptr, doubts, n_doubts);
+	} else
+		launch_batch_closest(ctx->stream, tree_of(ctx), rays, (uint64_t)n, hits, ctx->stack_depth, nullptr, order);
 	HIP_TRY(ctx, hipGetLastError());
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	return RTA_OK;

@@ -506,10 +506,13 @@ static int tracing_order(rta_context *ctx, const float *d_rays, int64_t n, const
 	         *sorted = (uint32_t *)(base + 3 * each), *descents = (uint32_t *)(base + 4 * each + temp);
 	launch_ray_keys(ctx->stream, d_rays, count, ctx->box, ctx->box + 3, keys, index, descents);
 	// a batch that comes in order (a camera's rays, say) is not sorted again
-	uint32_t out_of_order = 0;
-	HIP_TRY(ctx, hipMemcpyAsync(&out_of_order, descents, sizeof out_of_order, hipMemcpyDeviceToHost, ctx->stream));
+	uint32_t counters[kDescentCounters];
+	HIP_TRY(ctx, hipMemcpyAsync(counters, descents, sizeof counters, hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-	if ((uint64_t)out_of_order * 16 < count)
+	uint64_t out_of_order = 0;
+	for (uint32_t c : counters)
+		out_of_order += c;
+	if (out_of_order * 16 < count)
 		return RTA_OK;
 	HIP_TRY(ctx, launch_ray_sort(ctx->stream, count, keys, keys_sorted, index, sorted, base + 4 * each, temp));
 	order = sorted;

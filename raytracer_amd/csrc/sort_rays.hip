@@ -42,8 +42,9 @@ __device__ inline uint32_t ray_key(const float *r, const float lo_x, const float
 	return (cell << 3) | octant;
 }
 
-// keys[i], index[i] = i, and in *descents the number of rays whose key is below
-// the key of the ray before them (0 for a batch that is in order already)
+// keys[i], index[i] = i, and in descents[0..kDescentCounters) together the number of rays whose key is below
+// the key of the ray before them (0 for a batch that is in order already).  Several counters, because a
+// million waves adding to one word queue up behind one another (12 ms for 64 Mi incoherent rays).
 __global__ __launch_bounds__(kBlock) void k_ray_keys(const float *rays, const uint32_t n, const float lo_x, const float lo_y,
                                                     const float lo_z, const float sx, const float sy, const float sz,
                                                     uint32_t *keys, uint32_t *index, uint32_t *descents)
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(kBlock) void k_ray_keys(const float *rays, const ui
 	}
 	const unsigned long long votes = __ballot(descent);
 	if ((threadIdx.x & 63) == 0 && votes)
-		atomicAdd(descents, (uint32_t)__popcll(votes));
+		atomicAdd(descents + (blockIdx.x * (kBlock / 64) + threadIdx.x / 64) % kDescentCounters, (uint32_t)__popcll(votes));
 }
 
 }  // namespace
@@ -79,7 +80,7 @@ void launch_ray_keys(hipStream_t s, const float *rays, uint32_t n, const float b
 		const float extent = box_hi[k] - box_lo[k];
 		scale[k] = extent > 0.f ? 128.f / extent : 0.f;
 	}
-	(void)hipMemsetAsync(descents, 0, sizeof(uint32_t), s);
+	(void)hipMemsetAsync(descents, 0, kDescentCounters * sizeof(uint32_t), s);
 	hipLaunchKernelGGL(k_ray_keys, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, rays, n, box_lo[0], box_lo[1], box_lo[2],
 	                   scale[0], scale[1], scale[2], keys, index, descents);
 }

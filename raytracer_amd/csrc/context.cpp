@@ -1122,8 +1122,11 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		}
 		for (int g = 0; g < groups; g++) {
 			const Counters &c = ctx->host_counters[g];
-			st.rays += c.rays + c.early;
-			st.early_rays += c.early;
+			uint64_t early = 0;
+			for (unsigned long long e : c.early)
+				early += e;
+			st.rays += c.rays + early;
+			st.early_rays += early;
 			st.shadow_rays += c.shadow_rays;
 			st.inner_visits += c.inner;
 			st.tri_tests += c.tri;

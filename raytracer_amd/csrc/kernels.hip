@@ -549,7 +549,7 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 	for (int m = 32; m >= 1; m >>= 1)
 		answered_here += __shfl_xor(answered_here, m);
 	if (answered_here && lane == 0)
-		atomicAdd(&a.cnt->early, (unsigned long long)answered_here);
+		atomicAdd(&a.cnt->early[(blockIdx.x * (kBlock / 64) + threadIdx.x / 64) % kShards], (unsigned long long)answered_here);
 
 	// camera rays are coherent (a wave's rays cross one tile), bounce rays are not:
 	// they are queued apart so that a traversal wave holds rays of one kind

@@ -27,7 +27,9 @@ struct Counters {
 	alignas(8) uint32_t n_ray[2 * kRayKinds * kShards];
 	uint32_t head[2 * kShards * 2];              // queue entries already drawn by traversal waves, [step parity][shard][bounce, camera]
 	unsigned long long inner, tri, sph;     // RTA_RENDER_COUNT_WORK only
-	unsigned long long early;               // closest-hit queries answered where the ray was generated
+	// closest-hit queries answered where the ray was generated; the sum of the words counts (every wave of an
+	// advance launch may add to it: on ONE word they would queue up behind one another)
+	unsigned long long early[kShards];
 	unsigned long long retraced;            // closest-hit queries that the certified walk left to the exact traversal
 	unsigned long long walked;              // closest-hit queries handed to the certified walk (retraced ones included)
 };

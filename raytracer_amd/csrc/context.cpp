@@ -797,7 +797,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	const size_t group_bounce = (size_t)2 * kShards * shard_cap * 2;      // quads
 	HIP_TRY(ctx, ctx->q_bounce.reserve(group_bounce * groups * 16));
 	if (ctx->n_lights > 0)
-		HIP_TRY(ctx, ctx->shadow.reserve(S * 48));
+		HIP_TRY(ctx, ctx->shadow.reserve((size_t)groups * kShards * shard_cap * 48));      // kShards sub-queues per group
 	// Block sums are kept until their pixel's earlier blocks are in, 16 bytes per
 	// (pixel, block).  Beyond the budget the samples are rendered in passes over
 	// consecutive groups of blocks, each pass continuing the pixels' sums.
@@ -912,7 +912,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		a.meta = ctx->meta.as<uint4>() + off;
 		if (base.hint)
 			a.hint = base.hint + off;
-		a.shadow = ctx->shadow.as<float4>() ? ctx->shadow.as<float4>() + 3 * off : nullptr;
+		a.shadow = ctx->shadow.as<float4>() ? ctx->shadow.as<float4>() + 3 * (size_t)g * kShards * shard_cap : nullptr;
 		a.q_ray = ctx->q_ray.as<uint32_t>() + (size_t)g * group_queue;
 		a.q_bounce = ctx->q_bounce.as<float4>() + (size_t)g * group_bounce;
 		a.shard_cap = shard_cap;
@@ -1081,7 +1081,6 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		}
 		bool done = false;
 		int poll = 16;
-		std::vector<uint32_t> live_slots((size_t)groups, group_slots);      // slots of each group that can still hold a path
 		while (!done) {
 			for (int k = 0; k < poll; k++) {
 				for (int g = 0; g < groups; g++) {
@@ -1092,7 +1091,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 					HIP_TRY_R(timed(gs[g], 2, [&] { launch_advance(gs[g], a, par); }));
 					if (lights)
 						HIP_TRY_R(timed(gs[g], 1, [&] {
-							launch_shadow(gs[g], a, live_slots[g], ctx->stack_depth, count_work);
+							launch_shadow(gs[g], a, ctx->stack_depth, count_work);
 						}));
 					HIP_TRY_R(timed(gs[g], 0, [&] { launch_intersect(gs[g], a, par, ctx->stack_depth, count_work); }));
 				}
@@ -1114,7 +1113,6 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 				// traversal grids shrink with the work instead of covering the queues' capacity.
 				const uint64_t bound = ((uint64_t)waves * 64 + 255) / 256 * 256;
 				ga[g].grid_cap = (uint32_t)std::min<uint64_t>(shard_cap, std::max<uint64_t>(bound, 256));
-				live_slots[g] = (uint32_t)std::min<uint64_t>(group_slots, std::max<uint64_t>(bound, 256));
 			}
 			// near the end the host looks more often: steps past the end are empty launches
 			if (live * 64 * 8 < n_slots)

@@ -555,9 +555,10 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 	// they are queued apart so that a traversal wave holds rays of one kind
 	ray_queues_push(a, par, need_ray, alive, slot, next_ray);
 	if (a.n_lights > 0) {
-		const uint32_t at_sh = queue_push(want_shadow, &a.cnt->n_shadow);
+		const uint32_t shard = blockIdx.x % kShards;
+		const uint32_t at_sh = queue_push(want_shadow, &a.cnt->n_shadow[shard]);
 		if (want_shadow) {
-			float4 *e = a.shadow + 3 * (size_t)at_sh;
+			float4 *e = a.shadow + 3 * ((size_t)shard * a.shard_cap + at_sh);
 			e[0] = f4(sh_o, sh_dist);
 			e[1] = f4u(sh_d, slot);      // slot < n_slots here: want_shadow implies a live lane
 			e[2] = f4(sh_c, 0.f);
@@ -584,8 +585,8 @@ RTA_DEV void step_housekeeping(const RenderArgs &a, int par)
 	if (threadIdx.x < 2 * kShards)
 		a.cnt->head[(uint32_t)(par ^ 1) * 2 * kShards + threadIdx.x] = 0;
 
-	if (threadIdx.x == 0)
-		a.cnt->n_shadow = 0;
+	if (threadIdx.x < kShards)
+		a.cnt->n_shadow[threadIdx.x] = 0;
 }
 
 // Bounce rays are traced by few waves per sub-queue (one per rays_per_lane x 64
@@ -753,13 +754,15 @@ template <bool COUNT, bool LEAFWISE>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_shadow(const RenderArgs a, const int depth)
 {
 	extern __shared__ uint32_t lds_stack[];
-	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-	const uint32_t n = a.cnt->n_shadow;
-	if (i == 0)
+	// grid: shards innermost, as the ray queues' (kShards x grid_cap / kBlock workgroups)
+	const uint32_t shard = blockIdx.x % kShards, part = blockIdx.x / kShards;
+	const uint32_t i = part * kBlock + threadIdx.x;
+	const uint32_t n = a.cnt->n_shadow[shard];
+	if (i == 0 && n)
 		atomicAdd(&a.cnt->shadow_rays, (unsigned long long)n);
 	WorkCount wc = {0, 0, 0};
 	if (i < n) {
-		const float4 *e = a.shadow + 3 * (size_t)i;
+		const float4 *e = a.shadow + 3 * ((size_t)shard * a.shard_cap + i);
 		const float4 e0 = e[0], e1 = e[1], e2 = e[2];
 		Ray ray = {xyz(e0), xyz(e1)};
 		HitRec h;
@@ -826,14 +829,16 @@ RTA_DEV void occluded_by_walk(const DeviceTree &tree, uint32_t *stack, const int
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_shadow_walk(const RenderArgs a, const int depth)
 {
 	extern __shared__ uint32_t lds_stack[];
-	const uint32_t n = a.cnt->n_shadow;
-	if (blockIdx.x == 0 && threadIdx.x == 0)
+	const uint32_t shard = blockIdx.x % kShards, part = blockIdx.x / kShards;
+	const uint32_t n = a.cnt->n_shadow[shard];
+	if (part == 0 && threadIdx.x == 0 && n)
 		atomicAdd(&a.cnt->shadow_rays, (unsigned long long)n);
-	const uint32_t begin = (blockIdx.x * (kBlock / 64) + threadIdx.x / 64) * 64;
+	const uint32_t begin = (part * (kBlock / 64) + threadIdx.x / 64) * 64;
 	if (begin >= n)
 		return;
+	const float4 *queue = a.shadow + 3 * (size_t)shard * a.shard_cap;
 	const auto fetch = [&](uint32_t i, Ray &ray, float &limit) {
-		const float4 *e = a.shadow + 3 * (size_t)i;
+		const float4 *e = queue + 3 * (size_t)i;
 		const float4 e0 = e[0], e1 = e[1];
 		ray = Ray{xyz(e0), xyz(e1)};
 		limit = e0.w;
@@ -848,7 +853,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
 	    [&](uint32_t i, bool occluded) {
 		    if (!occluded) {
 			    // src/main.cpp:569: the light's contribution joins the path radiance
-			    const float4 *e = a.shadow + 3 * (size_t)i;
+			    const float4 *e = queue + 3 * (size_t)i;
 			    const float4 e1 = e[1], e2 = e[2];
 			    const uint32_t slot = __float_as_uint(e1.w);
 			    float4 C = a.col[slot];
@@ -1331,19 +1336,20 @@ void launch_intersect(hipStream_t s, const RenderArgs &a, int par, int depth, bo
 		                   depth);
 }
 
-void launch_shadow(hipStream_t s, const RenderArgs &a, uint32_t bound, int depth, bool count)
+void launch_shadow(hipStream_t s, const RenderArgs &a, int depth, bool count)
 {
+	// (the same bound per sub-queue as the ray queues')
+	const unsigned blocks = kShards * (a.grid_cap / kBlock);
 	if (a.wide_cap && !count)
-		hipLaunchKernelGGL(k_shadow_walk, dim3(blocks_for(bound)), dim3(kBlock), stack_bytes(std::max(depth, (int)a.wide_cap)), s, a,
-		                   depth);
+		hipLaunchKernelGGL(k_shadow_walk, dim3(blocks), dim3(kBlock), stack_bytes(std::max(depth, (int)a.wide_cap)), s, a, depth);
 	else if (count && a.leafwise)
-		hipLaunchKernelGGL((k_shadow<true, true>), dim3(blocks_for(bound)), dim3(kBlock), stack_bytes(depth), s, a, depth);
+		hipLaunchKernelGGL((k_shadow<true, true>), dim3(blocks), dim3(kBlock), stack_bytes(depth), s, a, depth);
 	else if (count)
-		hipLaunchKernelGGL((k_shadow<true, false>), dim3(blocks_for(bound)), dim3(kBlock), stack_bytes(depth), s, a, depth);
+		hipLaunchKernelGGL((k_shadow<true, false>), dim3(blocks), dim3(kBlock), stack_bytes(depth), s, a, depth);
 	else if (a.leafwise)
-		hipLaunchKernelGGL((k_shadow<false, true>), dim3(blocks_for(bound)), dim3(kBlock), stack_bytes(depth), s, a, depth);
+		hipLaunchKernelGGL((k_shadow<false, true>), dim3(blocks), dim3(kBlock), stack_bytes(depth), s, a, depth);
 	else
-		hipLaunchKernelGGL((k_shadow<false, false>), dim3(blocks_for(bound)), dim3(kBlock), stack_bytes(depth), s, a, depth);
+		hipLaunchKernelGGL((k_shadow<false, false>), dim3(blocks), dim3(kBlock), stack_bytes(depth), s, a, depth);
 }
 
 void launch_sum_blocks(hipStream_t s, const float4 *partial, const int32_t *pixels, uint32_t n_pad, uint32_t n_blocks,

@@ -17,7 +17,7 @@ constexpr uint32_t kRayKinds = 4;     // camera rays, bounce rays, rays needing 
 
 // Device-resident progress and statistics of one slot group (see RenderArgs).
 struct Counters {
-	uint32_t n_shadow;       // pending occlusion queries
+	uint32_t unused0;
 	uint32_t next_item;      // streams of the group's list already handed out
 	uint32_t live;           // waves that still have or may get work
 	uint32_t pad;
@@ -25,6 +25,7 @@ struct Counters {
 	// closest-hit queue lengths, [step parity][shard][kind]: the camera and the bounce counter of a
 	// shard are the halves of one aligned 64-bit word, which k_advance bumps with a single atomic
 	alignas(8) uint32_t n_ray[2 * kRayKinds * kShards];
+	uint32_t n_shadow[kShards];                  // pending occlusion queries per sub-queue (one counter would have every wave of an advance launch wait in line for it)
 	uint32_t head[2 * kShards * 2];              // queue entries already drawn by traversal waves, [step parity][shard][bounce, camera]
 	unsigned long long inner, tri, sph;     // RTA_RENDER_COUNT_WORK only
 	// closest-hit queries answered where the ray was generated; the sum of the words counts (every wave of an
@@ -149,8 +150,7 @@ constexpr int kSkyBorder = 3;     // cells around the frame that the cover map i
 void launch_sky_map(hipStream_t s, const TreeRef &tree, uint32_t n_pairs, const Projection &pr, uint32_t width,
                     uint32_t height, uint8_t *cover, float *sky_map);
 void launch_intersect(hipStream_t s, const RenderArgs &a, int par, int depth, bool count);
-// `bound`: an upper bound on the number of queued occlusion queries
-void launch_shadow(hipStream_t s, const RenderArgs &a, uint32_t bound, int depth, bool count);
+void launch_shadow(hipStream_t s, const RenderArgs &a, int depth, bool count);
 void launch_sum_blocks(hipStream_t s, const float4 *partial, const int32_t *pixels, uint32_t n_pad, uint32_t n_blocks,
                        float *frame, bool resume);
 void launch_resolve(hipStream_t s, const float *frame, const int32_t *pixels, uint32_t n, float samples, float exposure,

@@ -870,6 +870,10 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	base.leafwise = (uint64_t)ctx->n_prims >= 4 * ((uint64_t)ctx->n_pairs + 1) ? 1u : 0u;
 	// Bounce rays take the certified walk over the wide tree where the scene has one (triangles
 	// only, short leaves); 20 LDS entries per lane keep 8 workgroups on a CU
+	{
+		static const char *sort_lanes = getenv("RTA_SORT_LANES");      // measurement
+		base.sort_lanes = sort_lanes ? (uint32_t)atoi(sort_lanes) : (ctx->n_lights > 0 ? 1u : 0u);
+	}
 	base.wide_cap = (ctx->have_wide && !base.leafwise && !(p->flags & RTA_RENDER_EXACT_ONLY)) ? 20u : 0u;
 	// Camera rays join them when the camera (a pinhole) lies within the wide tree's reach; each starts
 	// with the triangle that the slot's last camera ray hit: the same pixel, most often the same triangle
@@ -1044,7 +1048,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		const uint32_t end_block = (uint32_t)std::min<uint64_t>(range_end, (uint64_t)range_begin + (uint64_t)g1 * blocks_per_group);
 		for (int g = 0; g < kMaxGroups; g++) {
 			memset(&ctx->host_counters[g], 0, sizeof(Counters));
-			ctx->host_counters[g].live = g < groups ? group_slots / 64 : 0;
+			ctx->host_counters[g].live = g < groups ? group_slots : 0;
 		}
 		HIP_TRY_R(hipMemcpyAsync(ctx->counters.ptr, ctx->host_counters, sizeof(Counters) * kMaxGroups, hipMemcpyHostToDevice, s));
 		HIP_TRY_R(hipStreamSynchronize(s));       // host_counters is reused for read-back below; the groups are idle
@@ -1105,17 +1109,17 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 			uint64_t live = 0;
 			for (int g = 0; g < groups; g++) {
 				HIP_TRY_R(hipStreamSynchronize(gs[g]));
-				const uint32_t waves = ctx->host_counters[g].live;
-				done = done && waves == 0;
-				live += waves;
-				// A wave that has retired stays retired for the rest of the pass, so the 64 slots of
-				// each wave still live bound what any sub-queue can receive from now on: the
-				// traversal grids shrink with the work instead of covering the queues' capacity.
-				const uint64_t bound = ((uint64_t)waves * 64 + 255) / 256 * 256;
+				const uint32_t slots = ctx->host_counters[g].live;
+				done = done && slots == 0;
+				live += slots;
+				// A slot that has retired stays retired for the rest of the pass, so the slots still
+				// live bound what any sub-queue can receive from now on: the traversal grids shrink
+				// with the work instead of covering the queues' capacity.
+				const uint64_t bound = ((uint64_t)slots + 255) / 256 * 256;
 				ga[g].grid_cap = (uint32_t)std::min<uint64_t>(shard_cap, std::max<uint64_t>(bound, 256));
 			}
 			// near the end the host looks more often: steps past the end are empty launches
-			if (live * 64 * 8 < n_slots)
+			if (live * 8 < n_slots)
 				poll = 4;
 		}
 		for (int g = 0; g < groups; g++) {

@@ -233,10 +233,62 @@ RTA_DEV bool misses_the_scene(const TreeRef &tree, const Ray &r)
 // the rays queued here.
 __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const int par)
 {
-	const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+	uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
 	const uint32_t lane = threadIdx.x & 63;
-	float4 r1 = make_float4(0.f, 0.f, 0.f, __uint_as_float(kRetired));
-	if (slot < a.n_slots)
+	float4 r1 = make_float4(0.f, 0.f, 0.f, __uint_as_float(kRetired)), H = make_float4(0.f, 0.f, 0.f, 0.f);
+	if (a.sort_lanes) {
+		// Which slot a lane works on is free (all state lives in memory, indexed by slot), and what a
+		// slot needs differs widely: a bounce to shade, a finished sample to retire and a camera ray to
+		// make, or nothing.  Left where they are, the kinds mix in every wave and each wave runs every
+		// branch with half its lanes off.  So the workgroup's lanes trade slots first: slots to shade
+		// go to the first lanes, slots with nothing to do to the middle, slots to retire and regenerate
+		// to the last - a wave then holds one kind of work, two where the kinds meet.  What the trade
+		// costs is coalescing: a wave's loads and stores then touch four times the lines, which pays
+		// only where shading is heavy (scenes with lights).
+		__shared__ uint32_t traded[kBlock];
+		__shared__ float4 traded_r1[kBlock], traded_hit[kBlock];
+		__shared__ uint32_t counts[kBlock / 64][2];
+		float4 own_r1 = make_float4(0.f, 0.f, 0.f, __uint_as_float(kRetired)), own_hit = make_float4(0.f, 0.f, 0.f, 0.f);
+		if (slot < a.n_slots)
+			own_r1 = a.ray1[slot];
+		const uint32_t st = __float_as_uint(own_r1.w);
+		// 0: shade, 1: nothing, 2: retire / draw a stream / generate
+		int kind = 1;
+		if (st < kWaiting) {
+			own_hit = a.hit[slot];
+			kind = __float_as_int(own_hit.x) < 0 ? 2 : 0;
+		} else if (st != kRetired)
+			kind = 2;
+		const unsigned long long shade = __ballot(kind == 0), idle = __ballot(kind == 1);
+		if (lane == 0) {
+			counts[threadIdx.x / 64][0] = (uint32_t)__popcll(shade);
+			counts[threadIdx.x / 64][1] = (uint32_t)__popcll(idle);
+		}
+		__syncthreads();
+		uint32_t before0 = 0, before1 = 0, before2 = 0, total0 = 0, total1 = 0;
+		for (uint32_t w = 0; w < kBlock / 64; w++) {
+			const uint32_t n0 = counts[w][0], n1 = counts[w][1];
+			if (w < threadIdx.x / 64) {
+				before0 += n0;
+				before1 += n1;
+				before2 += 64 - n0 - n1;
+			}
+			total0 += n0;
+			total1 += n1;
+		}
+		if (total1 == kBlock)
+			return;               // nothing left in any of the workgroup's slots
+		const unsigned long long mine = kind == 0 ? shade : (kind == 1 ? idle : ~(shade | idle));
+		const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
+		const uint32_t to = rank + (kind == 0 ? before0 : (kind == 1 ? total0 + before1 : total0 + total1 + before2));
+		traded[to] = slot;
+		traded_r1[to] = own_r1;
+		traded_hit[to] = own_hit;
+		__syncthreads();
+		slot = traded[threadIdx.x];
+		r1 = traded_r1[threadIdx.x];
+		H = traded_hit[threadIdx.x];
+	} else if (slot < a.n_slots)
 		r1 = a.ray1[slot];
 	uint32_t state = __float_as_uint(r1.w);
 	if (__ballot(state != kRetired) == 0)
@@ -251,7 +303,8 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 
 	if (state < kWaiting) {
 		const uint32_t bounce = state & (kHasColour - 1);
-		const float4 H = a.hit[slot];
+		if (!a.sort_lanes)
+			H = a.hit[slot];
 		rng = a.rng[slot];
 		V3 thr = mk(1, 1, 1);
 		if (bounce > 0) {
@@ -486,13 +539,13 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 					state = kRetired;          // the list is dry
 				}
 			}
+			// slots that retire are through for the rest of the render
+			if (got < n_wait && lane == 0)
+				atomicSub(&a.cnt->live, n_wait - got);
 		}
 		// every lane retired (not so on entry): the wave is through
-		if (__ballot(state != kRetired) == 0) {
-			if (lane == 0)
-				atomicSub(&a.cnt->live, 1u);
+		if (__ballot(state != kRetired) == 0)
 			break;
-		}
 
 		bool answered = false;
 		if (need_ray && !have_ray) {

@@ -19,7 +19,7 @@ constexpr uint32_t kRayKinds = 4;     // camera rays, bounce rays, rays needing 
 struct Counters {
 	uint32_t unused0;
 	uint32_t next_item;      // streams of the group's list already handed out
-	uint32_t live;           // waves that still have or may get work
+	uint32_t live;           // slots that still hold or may get a path
 	uint32_t pad;
 	unsigned long long rays, shadow_rays;
 	// closest-hit queue lengths, [step parity][shard][kind]: the camera and the bounce counter of a
@@ -92,6 +92,7 @@ struct RenderArgs {
 	uint32_t rays_per_lane, refill_at;     // bounce-ray traversal: see traverse_pulling
 	uint32_t leafwise;             // the tree has long leaves: traverse_leafwise, one ray per lane (rays_per_lane = 1)
 	uint32_t walk_refill_at, walk_quorum, walk_waiting;      // traverse_wide_pulling's thresholds for the render's rays
+	uint32_t sort_lanes;           // k_advance: the lanes of a workgroup trade slots so that its waves hold one kind of work each
 	uint32_t camera_walk;          // camera rays take the certified walk too (the camera lies within the wide tree's reach)
 	int32_t *hint;                 //   and start with the triangle the slot's last camera ray hit, [slot]; -1: none
 	uint32_t wide_cap;             // > 0: bounce rays take the certified walk over the wide tree, with this many LDS entries per lane

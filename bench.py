@@ -377,6 +377,9 @@ def roofline(w, excl, count, m):
                                    "visit counts averaged over every closest-hit query of the workload",
            "timing": "HIP events around every launch of an extra render on ONE stream (nothing overlaps), untimed for "
                      "`value`",
+           "frac_note": ("`achieved` prices every query at the reference traversal's algorithmic bytes; the kernel serves "
+                         "them from its caches (`traffic`, `hbm_frac_from_counters`, `l2_frac`), which is how the figure "
+                         "can pass the HBM peak on a scene of a few kilobytes") if achieved > HBM_PEAK_GBS else None,
            "exclusive_pass": {"gpu_ms": excl["gpu_ms"], "intersect_ms": excl["intersect_ms"],
                               "advance_ms": excl["advance_ms"], "shadow_ms": excl["shadow_ms"],
                               "advance_launches": excl["advance_launches"],

@@ -58,7 +58,8 @@ struct TreeRef {
 constexpr uint32_t kWideLeaf = 0x80000000u;     // child reference of a wide node: kWideLeaf | primitive,
 constexpr uint32_t kWideNone = 0xffffffffu;     //   a node number, or kWideNone for an empty child
 constexpr float kWideMaxDir = 2.f;              // longest ray direction the wide tree's padding is computed for
-constexpr int kBatchWalkCap = 20;               // entries of a lane's LDS column (node stack + triangle list) in k_batch_walk
+constexpr int kBatchWalkCap = 22;               // entries of a lane's LDS column (node stack + triangle list) in the batch walks:
+                                                //   seven workgroups (their registers' limit) fill a CU's 160 KB of LDS
 
 // Everything a wavefront kernel needs, passed by value.  The slot pool is cut
 // into groups that run their wavefront steps on different HIP streams, so that

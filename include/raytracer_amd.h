@@ -178,9 +178,11 @@ typedef struct {
  * order; hits[i] always belongs to ray i. */
 int rta_trace_closest(rta_context *ctx, const float *rays, int64_t n, rta_hit *hits, int mem);
 
-/* rta_trace_closest for callers that cannot allocate device memory (code under
- * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  It
- * has no counterpart in the reference.  rays and hits are DEVICE pointers on
+/* rta_trace_closest for callers that cannot allocate device memory (tight
+ * serving loops, harnesses that forbid hipMalloc).  It has no counterpart in
+ * the reference.  Like every compute call it runs on the context's own stream
+ * and returns when the work is done, so it is not itself capturable into a
+ * caller's HIP graph.  rays and hits are DEVICE pointers on
  * the context's GPU; results equal rta_trace_closest's bit for bit.  The batch
  * is traced in the order of its rays' origins, and the workspace for that order
  * (16 bytes per ray + the sort's temporary storage) is a fixed array in device
@@ -191,6 +193,34 @@ int rta_trace_closest(rta_context *ctx, const float *rays, int64_t n, rta_hit *h
  * in time on one GPU (from several contexts or threads) race. */
 #define RTA_STATIC_MAX_RAYS (1 << 20)
 int rta_trace_closest_static(rta_context *ctx, const float *rays, int64_t n, rta_hit *hits);
+
+/* What the last rta_trace_closest call on this context did, kernel by
+ * kernel: HIP events recorded on the context's stream
+ * around the launches.  The reference has no counterpart (it carries neither
+ * timing code nor ray counters, src/main.cpp:594-720); benchmarks price the
+ * traversal kernels with it.  The work counts are filled only by a call whose
+ * `mem` argument carried RTA_TRACE_COUNT_WORK (slower kernels). */
+enum {                                /* OR-ed into the `mem` argument of rta_trace_closest */
+	RTA_TRACE_COUNT_WORK = 0x100,     /* count node visits and primitive tests (rta_batch_stats) */
+	RTA_TRACE_EXACT_ONLY = 0x200      /* every ray through the traversal that replays the reference's visit order, as
+	                                   * RTA_RENDER_EXACT_ONLY does for a render (same hits either way) */
+};
+
+typedef struct {
+	int64_t rays;
+	int32_t sorted;               /* the batch was traced in the order of its rays' origins */
+	int32_t walked;               /* the batch went through the walk over the wide tree first */
+	uint64_t retraced_rays;       /* of a walked batch: rays left to the order-replaying traversal */
+	double order_ms;              /* sort keys and radix sort */
+	double walk_ms;               /* the walk's kernel */
+	double replay_ms;             /* the order-replaying kernel (the whole batch when !walked) */
+	uint64_t walk_node_visits;    /* 64-byte nodes of the wide tree read by the walk */
+	uint64_t walk_tri_tests;      /* triangle records (48 bytes) tested by the walk */
+	uint64_t replay_node_visits;  /* 64-byte pair records read by the order-replaying traversal */
+	uint64_t replay_prim_tests;   /* primitive records (48 bytes) it tested */
+} rta_batch_stats;
+
+int rta_last_batch_stats(const rta_context *ctx, rta_batch_stats *out);
 
 /* Any hit closer than tmax[i].  Replaces Occluded (src/main.cpp:424-478). */
 int rta_trace_occluded(rta_context *ctx, const float *rays, const float *tmax, int64_t n, uint8_t *out, int mem);

@@ -22,6 +22,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 PRIM_TRIANGLE, PRIM_SPHERE = 0, 1
 RENDER_TIME_KERNELS, RENDER_COUNT_WORK, RENDER_SMALL_PASSES, RENDER_EXACT_ONLY = 1, 2, 4, 8
 STATIC_MAX_RAYS = 1 << 20
+TRACE_COUNT_WORK, TRACE_EXACT_ONLY = 0x100, 0x200
 
 OK = 0
 E_INVALID, E_PARSE, E_IO, E_NO_DEVICE, E_DEVICE, E_NO_SCENE, E_LIMIT = -1, -2, -3, -4, -5, -6, -7
@@ -76,6 +77,16 @@ class Stats(C.Structure):
         return {name: getattr(self, name) for name, _ in self._fields_}
 
 
+class BatchStats(C.Structure):
+    _fields_ = [("rays", C.c_int64), ("sorted", C.c_int32), ("walked", C.c_int32), ("retraced_rays", C.c_uint64),
+                ("order_ms", C.c_double), ("walk_ms", C.c_double), ("replay_ms", C.c_double),
+                ("walk_node_visits", C.c_uint64), ("walk_tri_tests", C.c_uint64),
+                ("replay_node_visits", C.c_uint64), ("replay_prim_tests", C.c_uint64)]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
 HIT_DTYPE = np.dtype([("prim", "<i4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
 
 # name -> (restype, argtypes); also the list of symbols the header declares
@@ -101,6 +112,7 @@ _SIGNATURES = {
     "rta_upload_scene": (C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),
     "rta_trace_closest": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]),
     "rta_trace_closest_static": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "rta_last_batch_stats": (C.c_int, [C.c_void_p, C.POINTER(BatchStats)]),
     "rta_trace_occluded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]),
     "rta_render": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p, C.c_void_p,
                              C.POINTER(Stats)]),
@@ -380,8 +392,16 @@ class Context:
         self._check(lib().rta_trace_closest(self._h, rays.ctypes.data, rays.shape[0], hits.ctypes.data, MEM_HOST))
         return hits
 
-    def trace_closest_device(self, rays_ptr, n, hits_ptr):
-        self._check(lib().rta_trace_closest(self._h, rays_ptr, n, hits_ptr, MEM_DEVICE))
+    def trace_closest_device(self, rays_ptr, n, hits_ptr, count_work=False, exact_only=False):
+        self._check(lib().rta_trace_closest(self._h, rays_ptr, n, hits_ptr,
+                                            MEM_DEVICE | (TRACE_COUNT_WORK if count_work else 0) |
+                                            (TRACE_EXACT_ONLY if exact_only else 0)))
+
+    def last_batch_stats(self):
+        """What the last trace_closest call did, stage by stage (rta_last_batch_stats)."""
+        st = BatchStats()
+        self._check(lib().rta_last_batch_stats(self._h, C.byref(st)))
+        return st.as_dict()
 
     def trace_closest_static_device(self, rays_ptr, n, hits_ptr):
         """rta_trace_closest_static: device pointers, at most STATIC_MAX_RAYS rays, allocates nothing."""

@@ -66,16 +66,17 @@ int rta_create(int device, rta_context **out)
 		set_global_error(std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only");
 		return RTA_E_NO_DEVICE;
 	}
-	// this GPU's copy of the static workspace of rta_trace_closest_static (the device is current)
-	if ((e = static_scratch_init(device)) != hipSuccess) {
-		set_global_error(std::string("hipGetSymbolAddress(static workspace): ") + hipGetErrorString(e));
-		return RTA_E_DEVICE;
-	}
+	// this GPU's copy of the static workspace of rta_trace_closest_static (the device is current); a
+	// failed look-up only concerns that entry point, which tries again and reports it
+	(void)static_scratch_init(device);
 	rta_context *ctx = new rta_context();
 	ctx->device = device;
 	e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
 	for (int g = 0; g < kMaxGroups - 1 && e == hipSuccess; g++)
 		e = hipStreamCreateWithFlags(&ctx->extra[g], hipStreamNonBlocking);
+	for (hipEvent_t &ev : ctx->batch_ev)
+		if (e == hipSuccess)
+			e = hipEventCreate(&ev);
 	if (e != hipSuccess ||
 	    (e = hipHostMalloc((void **)&ctx->host_counters, sizeof(Counters) * kMaxGroups, hipHostMallocDefault)) != hipSuccess ||
 	    (e = ctx->counters.reserve(sizeof(Counters) * kMaxGroups)) != hipSuccess) {
@@ -101,6 +102,9 @@ void rta_destroy(rta_context *ctx)
 			(void)hipStreamSynchronize(x);
 			(void)hipStreamDestroy(x);
 		}
+	for (hipEvent_t ev : ctx->batch_ev)
+		if (ev)
+			(void)hipEventDestroy(ev);
 	if (ctx->host_counters)
 		(void)hipHostFree(ctx->host_counters);
 	delete ctx;
@@ -109,6 +113,14 @@ void rta_destroy(rta_context *ctx)
 const char *rta_last_error(const rta_context *ctx) { return ctx ? ctx->error.c_str() : get_global_error(); }
 
 void *rta_stream(rta_context *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int rta_last_batch_stats(const rta_context *ctx, rta_batch_stats *out)
+{
+	if (!ctx || !out)
+		return RTA_E_INVALID;
+	*out = ctx->batch;
+	return RTA_OK;
+}
 
 }  // extern "C"
 
@@ -487,6 +499,14 @@ int64_t rta_shard_pixels(int32_t width, int32_t height, int32_t shard_index, int
 
 // ------------------------------------------------------------------ ray batches
 
+// LDS entries per lane of the batch walks.  RTA_BATCH_CAP (measurement) may move it within what the walk
+// can work with: below 8 a visit finds no room for its four references, beyond 64 no workgroup fits a CU.
+static int batch_walk_cap()
+{
+	const char *v = getenv("RTA_BATCH_CAP");
+	return v ? std::min(std::max(atoi(v), 8), 64) : kBatchWalkCap;
+}
+
 // Big batches over a tree that does not fit the caches are traced in the order
 // of sort_rays.hip (same results, each ray is traced on its own).  Sets `order`
 // to the device array of ray numbers, or to null when the batch is traced as it
@@ -525,9 +545,13 @@ int rta_internal_trace_closest(rta_context *ctx, const float *rays, int64_t n, r
 {
 	if (!ctx)
 		return RTA_E_INVALID;
+	const bool count_work = (mem & RTA_TRACE_COUNT_WORK) != 0;
+	if (mem & RTA_TRACE_EXACT_ONLY)
+		walk = 0;
+	mem &= ~(RTA_TRACE_COUNT_WORK | RTA_TRACE_EXACT_ONLY);
 	if (!ctx->have_scene)
 		return ctx->fail(RTA_E_NO_SCENE, "no scene uploaded");
-	if (n < 0 || (n > 0 && (!rays || !hits)))
+	if (n < 0 || (n > 0 && (!rays || !hits)) || (mem != RTA_MEM_HOST && mem != RTA_MEM_DEVICE))
 		return ctx->fail(RTA_E_INVALID, "bad ray batch arguments");
 	if (n == 0)
 		return RTA_OK;
@@ -543,33 +567,72 @@ int rta_internal_trace_closest(rta_context *ctx, const float *rays, int64_t n, r
 		d_rays = ctx->io_a.as<const float>();
 		d_hits = ctx->io_b.as<rta_hit>();
 	}
+	rta_batch_stats bs;
+	memset(&bs, 0, sizeof bs);
+	bs.rays = n;
+	hipStream_t s = ctx->stream;
+	HIP_TRY(ctx, hipEventRecord(ctx->batch_ev[0], s));
 	const uint32_t *order = nullptr;
 	if (int rc = tracing_order(ctx, d_rays, n, order))
 		return rc;
+	bs.sorted = order != nullptr;
 	static const bool exact_only = getenv("RTA_BATCH_EXACT") != nullptr;      // measurement: price the walk
-	static const int cap = getenv("RTA_BATCH_CAP") ? atoi(getenv("RTA_BATCH_CAP")) : kBatchWalkCap;
+	static const int cap = batch_walk_cap();
+	// the work counts of a counting call: group 0's counters, which no render is using meanwhile
+	Counters *cnt = count_work ? ctx->counters.as<Counters>() : nullptr;
+	auto counted = [&](uint64_t &nodes, uint64_t &prims) -> hipError_t {
+		if (!cnt)
+			return hipSuccess;
+		hipError_t e = hipMemcpyAsync(ctx->host_counters, cnt, sizeof(Counters), hipMemcpyDeviceToHost, s);
+		if (e == hipSuccess)
+			e = hipStreamSynchronize(s);
+		nodes = ctx->host_counters->inner;
+		prims = ctx->host_counters->tri + ctx->host_counters->sph;
+		return e;
+	};
+	if (cnt)
+		HIP_TRY(ctx, hipMemsetAsync(cnt, 0, sizeof(Counters), s));
 	// the list of the rays the walk hands on: 4 bytes per ray; without room for it the batch is traced as before
 	const size_t list_bytes = ((size_t)n * 4 + 255) & ~(size_t)255;
 	if (walk && ctx->have_wide && n < ((int64_t)1 << 32) && !exact_only && ctx->doubts.reserve(list_bytes + 256) != hipSuccess) {
 		(void)hipGetLastError();
 		walk = false;
 	}
+	HIP_TRY(ctx, hipEventRecord(ctx->batch_ev[1], s));
 	if (walk && ctx->have_wide && n < ((int64_t)1 << 32) && !exact_only) {
 		// the certified walk answers what it can prove; the rest goes through the replaying traversal
 		uint32_t *list = ctx->doubts.as<uint32_t>(), *count = (uint32_t *)(ctx->doubts.as<char>() + list_bytes);
-		launch_batch_walk(ctx->stream, tree_of(ctx), d_rays, (uint64_t)n, d_hits, cap, order, list, count);
+		launch_batch_walk(s, tree_of(ctx), d_rays, (uint64_t)n, d_hits, cap, order, list, count, cnt);
 		HIP_TRY(ctx, hipGetLastError());
+		HIP_TRY(ctx, hipEventRecord(ctx->batch_ev[2], s));
 		uint32_t in_doubt = 0;
-		HIP_TRY(ctx, hipMemcpyAsync(&in_doubt, count, sizeof in_doubt, hipMemcpyDeviceToHost, ctx->stream));
-		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(&in_doubt, count, sizeof in_doubt, hipMemcpyDeviceToHost, s));
+		HIP_TRY(ctx, hipStreamSynchronize(s));
+		HIP_TRY(ctx, counted(bs.walk_node_visits, bs.walk_tri_tests));
+		if (cnt)
+			HIP_TRY(ctx, hipMemsetAsync(cnt, 0, sizeof(Counters), s));
+		bs.walked = 1;
+		bs.retraced_rays = in_doubt;
 		if (in_doubt)
-			launch_batch_closest(ctx->stream, tree_of(ctx), d_rays, (uint64_t)in_doubt, d_hits, ctx->stack_depth, nullptr, list);
-	} else
-		launch_batch_closest(ctx->stream, tree_of(ctx), d_rays, (uint64_t)n, d_hits, ctx->stack_depth, nullptr, order);
+			launch_batch_closest(s, tree_of(ctx), d_rays, (uint64_t)in_doubt, d_hits, ctx->stack_depth, cnt, list);
+	} else {
+		HIP_TRY(ctx, hipEventRecord(ctx->batch_ev[2], s));
+		launch_batch_closest(s, tree_of(ctx), d_rays, (uint64_t)n, d_hits, ctx->stack_depth, cnt, order);
+	}
 	HIP_TRY(ctx, hipGetLastError());
+	HIP_TRY(ctx, hipEventRecord(ctx->batch_ev[3], s));
 	if (mem == RTA_MEM_HOST)
-		HIP_TRY(ctx, hipMemcpyAsync(hits, d_hits, (size_t)n * sizeof(rta_hit), hipMemcpyDeviceToHost, ctx->stream));
-	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(hits, d_hits, (size_t)n * sizeof(rta_hit), hipMemcpyDeviceToHost, s));
+	HIP_TRY(ctx, hipStreamSynchronize(s));
+	HIP_TRY(ctx, counted(bs.replay_node_visits, bs.replay_prim_tests));
+	float ms = 0;
+	HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->batch_ev[0], ctx->batch_ev[1]));
+	bs.order_ms = ms;
+	HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->batch_ev[1], ctx->batch_ev[2]));
+	bs.walk_ms = ms;
+	HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->batch_ev[2], ctx->batch_ev[3]));
+	bs.replay_ms = ms;
+	ctx->batch = bs;
 	return RTA_OK;
 }
 
@@ -893,9 +956,11 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	// refill at 8 / 16 / 32 loses 4 / 1 / 0 %, quorum 16 or 32 loses 1 %, waiting 8 or 32 within 0.5 %.
 	{
 		static const char *refill = getenv("RTA_WALK_REFILL"), *quorum = getenv("RTA_WALK_QUORUM"), *waiting = getenv("RTA_WALK_WAITING");
-		base.walk_refill_at = refill ? (uint32_t)atoi(refill) : 24u;
-		base.walk_quorum = quorum ? (uint32_t)atoi(quorum) : 24u;
-		base.walk_waiting = waiting ? (uint32_t)atoi(waiting) : 16u;
+		// (a threshold beyond the 64 lanes of a wave would never be met: the walk's loop would spin)
+		auto lanes = [](const char *v, uint32_t fallback) { return v ? (uint32_t)std::min(std::max(atoi(v), 1), 64) : fallback; };
+		base.walk_refill_at = lanes(refill, 24u);
+		base.walk_quorum = lanes(quorum, 24u);
+		base.walk_waiting = lanes(waiting, 16u);
 	}
 	base.rays_per_lane = 8;       // measured on dragon.txt: 4 and 12 lose 1-2 %
 	base.refill_at = 24;          // likewise 16 (8 loses 3 %)

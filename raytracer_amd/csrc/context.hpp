@@ -80,6 +80,8 @@ struct rta_context {
 	rta::DeviceBuffer doubts;                 // rays a batch's certified walk hands on to the exact traversal
 	rta::DeviceBuffer io_a, io_b, io_c;       // staging for host-pointer calls
 	rta::Counters *host_counters = nullptr;   // pinned, kMaxGroups entries
+	hipEvent_t batch_ev[4] = {};              // around the stages of a ray batch: order, walk, replay (rta_last_batch_stats)
+	rta_batch_stats batch = {};               // what the last ray batch did
 
 	// What a render prepares before its first wavefront step depends only on the
 	// scene, the camera, the frame size and the shard: the owned pixel list, the

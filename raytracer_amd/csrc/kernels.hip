@@ -327,10 +327,12 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 			const float4 s0 = a.shade_prims[3 * (size_t)prim];
 			const float4 s1 = a.shade_prims[3 * (size_t)prim + 1];
 			const float4 s2 = a.shade_prims[3 * (size_t)prim + 2];
-			if (a.hint && bounce == 0)
-				a.hint[slot] = prim;      // the slot's next camera ray goes through the same pixel
 			const int32_t mat_id = __float_as_int(s0.w), light_id = __float_as_int(s1.w);
 			const bool is_sphere = __float_as_int(s2.w) == RTA_PRIM_SPHERE;
+			// the slot's next camera ray goes through the same pixel (hints are triangles: the walk
+			// tests every sphere anyway)
+			if (a.hint && bounce == 0)
+				a.hint[slot] = is_sphere ? -1 : prim;
 
 			// src/main.cpp:353-354,365-368
 			const V3 point = ray.o + ray.d * t;
@@ -1216,9 +1218,10 @@ __global__ __launch_bounds__(kBlock) void k_batch_closest(const DeviceTree tree,
 constexpr uint32_t kBatchWalkRefillAt = 24, kBatchWalkQuorum = 24, kBatchWalkWaiting = 64;
 
 // (seven waves per SIMD: at eight, 64 registers, the kernel spills ten of them in its loop)
+template <bool COUNT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_batch_walk(
     const DeviceTree tree, const float *rays, uint64_t n, rta_hit *hits, const int cap, const uint32_t rays_per_lane,
-    const uint32_t *order, uint32_t *doubts, uint32_t *n_doubts)
+    const uint32_t *order, uint32_t *doubts, uint32_t *n_doubts, Counters *cnt)
 {
 	extern __shared__ uint32_t lds_stack[];
 	const uint64_t per_wave = 64 * (uint64_t)rays_per_lane;
@@ -1228,7 +1231,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
 	const uint32_t *which = order ? order + begin : nullptr;
 	WorkCount wc = {0, 0, 0};
 	WideCensus cs = {0, 0, 0, 0, 0};
-	traverse_wide_pulling<false>(
+	traverse_wide_pulling<COUNT>(
 	    tree, kBatchWalkRefillAt, kBatchWalkQuorum, kBatchWalkWaiting, lds_stack + threadIdx.x, cap, wc, cs,
 	    OwnChunk{(uint32_t)(n - begin < per_wave ? n - begin : per_wave), 0u},
 	    [&](uint32_t i, Ray &ray, int32_t &hint) {
@@ -1253,6 +1256,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
 				                                            __builtin_amdgcn_mbcnt_lo((uint32_t)handed_on, 0u))] = number;
 		    }
 	    });
+	if (COUNT)
+		count_flush(cnt, wc);
 }
 
 __global__ __launch_bounds__(kBlock) void k_batch_occluded(const DeviceTree tree, const float *rays, const float *tmax,
@@ -1435,13 +1440,18 @@ void launch_batch_closest(hipStream_t s, const TreeRef &tree, const float *rays,
 }
 
 void launch_batch_walk(hipStream_t s, const TreeRef &tree, const float *rays, uint64_t n, rta_hit *hits, int cap,
-                       const uint32_t *order, uint32_t *doubts, uint32_t *n_doubts)
+                       const uint32_t *order, uint32_t *doubts, uint32_t *n_doubts, Counters *cnt)
 {
 	// long runs per wave once the batch fills the GPU several times over
 	const uint32_t rays_per_lane = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, n >> 20));
+	const dim3 grid(blocks_for((n + rays_per_lane - 1) / rays_per_lane));
 	(void)hipMemsetAsync(n_doubts, 0, sizeof(uint32_t), s);
-	hipLaunchKernelGGL(k_batch_walk, dim3(blocks_for((n + rays_per_lane - 1) / rays_per_lane)), dim3(kBlock), stack_bytes(cap), s,
-	                   tree, rays, n, hits, cap, rays_per_lane, order, doubts, n_doubts);
+	if (cnt)
+		hipLaunchKernelGGL(k_batch_walk<true>, grid, dim3(kBlock), stack_bytes(cap), s, tree, rays, n, hits, cap, rays_per_lane,
+		                   order, doubts, n_doubts, cnt);
+	else
+		hipLaunchKernelGGL(k_batch_walk<false>, grid, dim3(kBlock), stack_bytes(cap), s, tree, rays, n, hits, cap, rays_per_lane,
+		                   order, doubts, n_doubts, cnt);
 }
 
 void launch_batch_occluded_walk(hipStream_t s, const TreeRef &tree, const float *rays, const float *tmax, uint64_t n,

@@ -162,8 +162,9 @@ void launch_resolve(hipStream_t s, const float *frame, const int32_t *pixels, ui
 void launch_batch_closest(hipStream_t s, const TreeRef &tree, const float *rays, uint64_t n, rta_hit *hits, int depth,
                           Counters *cnt, const uint32_t *order = nullptr, const uint32_t *count_from = nullptr);
 // the certified walk over the wide tree; rays left in doubt are listed for launch_batch_closest (order = doubts)
+// (`cnt`: null, or where the walk adds its node visits and triangle tests)
 void launch_batch_walk(hipStream_t s, const TreeRef &tree, const float *rays, uint64_t n, rta_hit *hits, int cap,
-                       const uint32_t *order, uint32_t *doubts, uint32_t *n_doubts);
+                       const uint32_t *order, uint32_t *doubts, uint32_t *n_doubts, Counters *cnt = nullptr);
 // the any-hit walk over the wide tree (n < 2^32); queries it cannot answer for certain are traced exactly in the same launch
 void launch_batch_occluded_walk(hipStream_t s, const TreeRef &tree, const float *rays, const float *tmax, uint64_t n,
                                 uint8_t *out, int cap, int depth, const uint32_t *order);

@@ -9,8 +9,10 @@
 //
 // In host code the array's NAME is only a handle for hipGetSymbolAddress: each
 // GPU has its own copy at its own address, looked up once per device
-// (static_scratch_init, called by rta_create with that device current) and
-// kept in g_scratch[device].  Everything below passes that pointer.
+// (static_scratch_init, called by rta_create with that device current, and
+// again by the entry point if that look-up failed) and kept in
+// g_scratch[device] until the process ends (a hipDeviceReset by the caller
+// invalidates it along with every context).  Everything below passes that pointer.
 //
 // All calls on one GPU share that GPU's array, so two such calls that overlap
 // in time on one GPU race, also from different contexts.  The array keeps the
@@ -82,13 +84,14 @@ extern "C" int rta_trace_closest_static(rta_context *ctx, const float *rays, int
 	if (n == 0)
 		return RTA_OK;
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	// (looked up when the context was created; if that failed, once more here: a look-up allocates nothing)
+	if (hipError_t e = static_scratch_init(ctx->device); e != hipSuccess)
+		return ctx->fail(RTA_E_DEVICE, std::string("the static workspace of this GPU was not found: hipGetSymbolAddress: ") + hipGetErrorString(e));
 	char *base = nullptr;
 	{
 		std::lock_guard<std::mutex> hold(g_lock);
-		base = ctx->device < kMaxDevices ? (char *)g_scratch[ctx->device] : nullptr;
+		base = (char *)g_scratch[ctx->device];
 	}
-	if (!base)
-		return ctx->fail(RTA_E_DEVICE, "the static workspace of this GPU was not found when the context was created");
 	const uint32_t count = (uint32_t)n;
 	const uint32_t *order = nullptr;
 	if (ctx->box_known) {

@@ -54,12 +54,29 @@ class ShardGather:
 
 
 def block_ranges(samples, samples_per_stream, world):
-    """[begin, end) sample-block range of every rank: the blocks cut into `world` near-equal runs
-    (empty, begin == end, for ranks beyond the number of blocks: such a rank renders nothing)."""
+    """The sample-block share of every rank: the blocks cut into `world` near-equal runs, each a
+    (begin, end) pair with begin < end - or None for a rank that gets no block (more ranks than
+    blocks).  A None share must not reach rta_render: there, block_begin == block_end == 0 asks for
+    ALL blocks.  render_share() below does the right thing for either."""
     # (samples_per_stream <= 0 means one stream, hence one block, per pixel: rta_render_params)
     n_blocks = 1 if samples_per_stream <= 0 else -(-samples // min(samples_per_stream, samples))
     cuts = [n_blocks * r // world for r in range(world + 1)]
-    return list(zip(cuts[:-1], cuts[1:]))
+    return [(a, b) if b > a else None for a, b in zip(cuts[:-1], cuts[1:])]
+
+
+def render_share(ctx, camera, params, share, frame):
+    """Renders one rank's share of the sample blocks (an entry of block_ranges) into `frame`, a
+    [height, width, 3] float32 device tensor that receives the partial radiance sums; a rank
+    without a share contributes zeros and renders nothing.  Returns the render's statistics."""
+    from . import Stats
+    if share is None:
+        frame.zero_()
+        if frame.is_cuda:
+            import torch
+            torch.cuda.current_stream(frame.device).synchronize()
+        return dict.fromkeys(Stats().as_dict(), 0)
+    params.block_begin, params.block_end = share
+    return ctx.render_device(camera, params, frame.data_ptr(), None)
 
 
 def reduce_partial_sums(frame, dist):

@@ -28,36 +28,7 @@ import torch
 import raytracer_amd as rta
 
 
-def make_soup(n, seed=1):
-    """Centres uniform in [-1,1]^3, vertices = centre + uniform [-0.01,0.01]^3."""
-    rng = np.random.default_rng(seed)
-    out = np.empty((n, 9), np.float32)
-    step = 1 << 20
-    for a in range(0, n, step):
-        m = min(step, n - a)
-        c = rng.uniform(-1, 1, (m, 1, 3)).astype(np.float32)
-        out[a:a + m] = (c + rng.uniform(-0.01, 0.01, (m, 3, 3)).astype(np.float32)).reshape(m, 9)
-    return out
-
-
-def coherent_rays(side, dev):
-    """A side x side pinhole grid from (-3, 0, 0) looking at the origin, 40 degrees wide."""
-    half = float(np.tan(np.radians(20.0)))
-    t = (torch.arange(side, device=dev, dtype=torch.float32) + 0.5) / side * 2 - 1
-    y = (t * half).view(1, side).expand(side, side)
-    z = (-t * half).view(side, 1).expand(side, side)
-    d = torch.stack([torch.ones_like(y), y, z], dim=-1).reshape(-1, 3)
-    d = d / d.norm(dim=1, keepdim=True)
-    o = torch.tensor([-3.0, 0.0, 0.0], device=dev).expand_as(d)
-    return torch.cat([o, d], dim=1).contiguous()
-
-
-def incoherent_rays(n, dev, seed=2):
-    g = torch.Generator(device=dev).manual_seed(seed)
-    o = torch.rand((n, 3), device=dev, generator=g) * 2 - 1
-    d = torch.randn((n, 3), device=dev, generator=g)
-    d = d / d.norm(dim=1, keepdim=True)
-    return torch.cat([o, d], dim=1).contiguous()
+from raytracer_amd.synthetic import coherent_rays, incoherent_rays, make_soup  # noqa: E402,F401
 
 
 def main():

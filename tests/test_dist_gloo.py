@@ -61,7 +61,7 @@ def _reduce_worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         # every rank contributes a frame that depends on its block range; the sum must be the same everywhere
-        b0, b1 = block_ranges(37, 4, world)[rank]
+        b0, b1 = block_ranges(37, 4, world)[rank]      # (10 blocks over 3 ranks: nobody is without)
         frame = torch.full((H, W, 3), float(b1 - b0), dtype=torch.float32) + torch.arange(H * W * 3).reshape(H, W, 3) * (rank + 1)
         reduce_partial_sums(frame, dist)
         np.save(os.path.join(out_dir, f"sum{rank}.npy"), frame.numpy())
@@ -73,7 +73,10 @@ def test_sample_range_reduce(tmp_path):
     world = 3
     ranges = block_ranges(37, 4, world)
     assert ranges[0][0] == 0 and ranges[-1][1] == 10 and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
-    assert block_ranges(8, 0, 2) == [(0, 0), (0, 1)] and block_ranges(8, 2, 2) == [(0, 2), (2, 4)]
+    # a rank without a block gets None, never the (0, 0) that rta_render reads as "all blocks"
+    assert block_ranges(8, 0, 2) == [None, (0, 1)] and block_ranges(8, 2, 2) == [(0, 2), (2, 4)]
+    assert block_ranges(8, 4, 5) == [None, None, (0, 1), None, (1, 2)]
+    assert all(r is None or r[0] < r[1] for w in range(1, 9) for r in block_ranges(20, 3, w))
     mp.spawn(_reduce_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     frames = [np.load(tmp_path / f"sum{r}.npy") for r in range(world)]
     want = 10.0 + np.arange(H * W * 3, dtype=np.float32).reshape(H, W, 3) * 6

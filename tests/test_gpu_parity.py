@@ -233,6 +233,42 @@ def test_sample_ranges_sum_to_the_whole_render(gpu, name, w, h, spp, sps):
         gpu.render(psc.camera(), w, h, spp, samples_per_stream=sps, block_begin=0, block_end=1)
 
 
+@pytest.mark.parametrize("sps,world", [(0, 2), (4, 5), (3, 8)])
+def test_more_ranks_than_sample_blocks(gpu, sps, world):
+    """Sample-range sharding with ranks that get no block (one block per pixel
+    split two ways; two blocks over five ranks; three over eight): such a rank
+    must contribute zeros, not the whole frame a second time (block range 0, 0
+    means "all blocks" to rta_render).  The shares of raytracer_amd.dist summed as
+    its all-reduce would sum them give the unsplit frame."""
+    import torch
+    from raytracer_amd.dist import block_ranges, render_share
+    w, h, spp = 40, 24, 8
+    osc, psc = load_pair("cornell_box.txt")
+    psc.set_render(w, h, spp)
+    gpu.upload(psc)
+    s = psc.settings
+    _, whole, whole_st = gpu.render_scene(psc, seed=5, samples_per_stream=sps)
+    shares = block_ranges(spp, sps, world)
+    assert sum(r is None for r in shares) == world - (1 if sps <= 0 else -(-spp // sps))
+    dev = torch.device("cuda", 0)
+    total = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
+    samples = 0
+    for share in shares:
+        frame = torch.full((h, w, 3), 7.0, dtype=torch.float32, device=dev)      # (stale contents must not survive)
+        torch.cuda.synchronize()
+        p = rta.RenderParams(width=w, height=h, samples=spp, exposure=s.exposure, seed=5, samples_per_stream=sps,
+                             shard_index=0, shard_count=1, out_mem=rta.MEM_DEVICE)
+        p.sky[:] = list(s.sky)
+        st = render_share(gpu, psc.camera(), p, share, frame)
+        torch.cuda.synchronize()
+        total += frame
+        samples += st["samples"]
+    assert samples == whole_st["samples"] == w * h * spp
+    got = total.cpu().numpy()
+    tol = 4 * np.spacing(np.maximum(np.abs(whole), np.float32(1e-6)).astype(np.float32))
+    assert (np.abs(got - whole) <= tol).all()
+
+
 def test_scheduling_knobs_do_not_change_the_image(gpu):
     osc, psc = load_pair("cornell_box.txt")
     psc.set_render(40, 24, 6)

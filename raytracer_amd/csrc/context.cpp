@@ -520,18 +520,19 @@ static int tracing_order(rta_context *ctx, const float *d_rays, int64_t n, const
 		return RTA_OK;
 	const uint32_t count = (uint32_t)n;
 	const size_t temp = (ray_order_temp_bytes(count) + 255) & ~(size_t)255, each = ((size_t)count * 4 + 255) & ~(size_t)255;
-	HIP_TRY(ctx, ctx->ray_order.reserve(4 * each + temp + 256));
+	constexpr uint32_t kStride = 64;      // words between two counters: each in a 128-byte line (and L2 channel) of its own
+	HIP_TRY(ctx, ctx->ray_order.reserve(4 * each + temp + (size_t)kDescentCounters * kStride * 4));
 	char *base = ctx->ray_order.as<char>();
 	uint32_t *keys = (uint32_t *)base, *keys_sorted = (uint32_t *)(base + each), *index = (uint32_t *)(base + 2 * each),
 	         *sorted = (uint32_t *)(base + 3 * each), *descents = (uint32_t *)(base + 4 * each + temp);
-	launch_ray_keys(ctx->stream, d_rays, count, ctx->box, ctx->box + 3, keys, index, descents);
+	launch_ray_keys(ctx->stream, d_rays, count, ctx->box, ctx->box + 3, keys, index, descents, kStride);
 	// a batch that comes in order (a camera's rays, say) is not sorted again
-	uint32_t counters[kDescentCounters];
+	uint32_t counters[kDescentCounters * kStride];
 	HIP_TRY(ctx, hipMemcpyAsync(counters, descents, sizeof counters, hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	uint64_t out_of_order = 0;
-	for (uint32_t c : counters)
-		out_of_order += c;
+	for (uint32_t k = 0; k < kDescentCounters; k++)
+		out_of_order += counters[k * kStride];
 	if (out_of_order * 16 < count)
 		return RTA_OK;
 	HIP_TRY(ctx, launch_ray_sort(ctx->stream, count, keys, keys_sorted, index, sorted, base + 4 * each, temp));
@@ -830,10 +831,10 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	want_waves = std::min<uint64_t>(want_waves, std::max<uint64_t>(items64, 1));
 	int groups = p->streams > 0 ? std::min(p->streams, kMaxGroups) : 4;
 	const uint64_t waves_per_block = 256 / 64;
-	uint64_t group_blocks = (want_waves + groups * waves_per_block - 1) / (groups * waves_per_block);
-	const uint32_t group_slots = (uint32_t)(group_blocks * 256);
-	const uint32_t n_slots = group_slots * (uint32_t)groups;
-	if (items64 + n_slots >= 0xffffffffull || (uint64_t)n_blocks * n_pad >= 0xffffffffull)
+	// (the workspace is sized for this many; how many of them the render uses is settled once the
+	// image's work is known, see below)
+	const uint64_t max_group_blocks = (want_waves + groups * waves_per_block - 1) / (groups * waves_per_block);
+	if (items64 + max_group_blocks * 256 * groups >= 0xffffffffull || (uint64_t)n_blocks * n_pad >= 0xffffffffull)
 		return ctx->fail(RTA_E_LIMIT, "tiles x sample blocks exceeds 2^32; raise samples_per_stream");
 	// A wave draws new streams when all its lanes are waiting.  Drawing earlier
 	// (measured at 4..32 waiting lanes) fills idle lanes but loses more than it
@@ -842,7 +843,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	const uint32_t grab_at = 64;
 
 	// workspace (grow-only, reused across calls)
-	const size_t S = n_slots;
+	const size_t S = (size_t)max_group_blocks * 256 * groups;
 	HIP_TRY(ctx, ctx->ray0.reserve(S * 16));
 	HIP_TRY(ctx, ctx->ray1.reserve(S * 16));
 	HIP_TRY(ctx, ctx->hit.reserve(S * 16));
@@ -852,15 +853,14 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	HIP_TRY(ctx, ctx->acc.reserve(S * 16));
 	HIP_TRY(ctx, ctx->meta.reserve(S * 16));
 	HIP_TRY(ctx, ctx->hint.reserve(S * 4));
-	// per group: 2 parities x kRayKinds kinds x kShards sub-queues, each able to take
-	// everything its share of the group's workgroups can append in one launch
-	const uint32_t shard_cap = (uint32_t)((group_blocks + kShards - 1) / kShards) * 256;
-	const size_t group_queue = (size_t)2 * kRayKinds * kShards * shard_cap;
-	HIP_TRY(ctx, ctx->q_ray.reserve(group_queue * groups * 4));
-	const size_t group_bounce = (size_t)2 * kShards * shard_cap * 2;      // quads
-	HIP_TRY(ctx, ctx->q_bounce.reserve(group_bounce * groups * 16));
-	if (ctx->n_lights > 0)
-		HIP_TRY(ctx, ctx->shadow.reserve((size_t)groups * kShards * shard_cap * 48));      // kShards sub-queues per group
+	// the ray queues, for the largest pool this call may use (their layout follows the pool, below)
+	{
+		const size_t max_cap = (size_t)((max_group_blocks + kShards - 1) / kShards) * 256;
+		HIP_TRY(ctx, ctx->q_ray.reserve((size_t)2 * kRayKinds * kShards * max_cap * groups * 4));
+		HIP_TRY(ctx, ctx->q_bounce.reserve((size_t)2 * kShards * max_cap * 2 * groups * 16));
+		if (ctx->n_lights > 0)
+			HIP_TRY(ctx, ctx->shadow.reserve((size_t)groups * kShards * max_cap * 48));      // kShards sub-queues per group
+	}
 	// Block sums are kept until their pixel's earlier blocks are in, 16 bytes per
 	// (pixel, block).  Beyond the budget the samples are rendered in passes over
 	// consecutive groups of blocks, each pass continuing the pixels' sums.
@@ -901,7 +901,6 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	base.materials = ctx->materials.as<const float4>();
 	base.lights = ctx->lights.as<const float4>();
 	base.n_lights = ctx->n_lights;
-	base.n_slots = group_slots;
 	base.partial = ctx->partial.as<float4>();
 	base.pixels = ctx->pixels.as<const int32_t>();
 	base.n_tiles = n_tiles;
@@ -965,31 +964,6 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	base.rays_per_lane = 8;       // measured on dragon.txt: 4 and 12 lose 1-2 %
 	base.refill_at = 24;          // likewise 16 (8 loses 3 %)
 
-	// one RenderArgs and one stream per slot group
-	std::vector<RenderArgs> ga((size_t)groups, base);
-	std::vector<hipStream_t> gs((size_t)groups);
-	for (int g = 0; g < groups; g++) {
-		const size_t off = (size_t)g * group_slots;
-		RenderArgs &a = ga[g];
-		a.ray0 = ctx->ray0.as<float4>() + off;
-		a.ray1 = ctx->ray1.as<float4>() + off;
-		a.hit = ctx->hit.as<float4>() + off;
-		a.thr = ctx->thr.as<float4>() + off;
-		a.col = ctx->col.as<float4>() + off;
-		a.rng = ctx->rng.as<uint32_t>() + off;
-		a.acc = ctx->acc.as<float4>() + off;
-		a.meta = ctx->meta.as<uint4>() + off;
-		if (base.hint)
-			a.hint = base.hint + off;
-		a.shadow = ctx->shadow.as<float4>() ? ctx->shadow.as<float4>() + 3 * (size_t)g * kShards * shard_cap : nullptr;
-		a.q_ray = ctx->q_ray.as<uint32_t>() + (size_t)g * group_queue;
-		a.q_bounce = ctx->q_bounce.as<float4>() + (size_t)g * group_bounce;
-		a.shard_cap = shard_cap;
-		a.grid_cap = shard_cap;
-		a.cnt = ctx->counters.as<Counters>() + g;
-		gs[g] = g == 0 ? ctx->stream : ctx->extra[g - 1];
-	}
-
 	const bool time_kernels = (p->flags & RTA_RENDER_TIME_KERNELS) != 0;
 	const bool count_work = (p->flags & RTA_RENDER_COUNT_WORK) != 0;
 	const bool lights = ctx->n_lights > 0;
@@ -1041,7 +1015,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		far_pixels = pre.far_pixels;
 	} else if (n_parts) {
 		std::vector<uint32_t> weight(n_parts), order(n_parts);
-		launch_part_weights(s, ga[0], ctx->part_weights.as<uint32_t>(), ctx->stack_depth);
+		launch_part_weights(s, base, ctx->part_weights.as<uint32_t>(), ctx->stack_depth);
 		HIP_TRY_R(hipMemcpyAsync(weight.data(), ctx->part_weights.ptr, (size_t)n_parts * 4, hipMemcpyDeviceToHost, s));
 		HIP_TRY_R(hipStreamSynchronize(s));
 		// parts that only see the sky come off the list: their block sums are written
@@ -1080,6 +1054,53 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	pre.n_far = n_far;
 	pre.far_pixels = far_pixels;
 	pre.valid = true;
+	// The slot pool.  Every pass of k_advance reads a word of every slot, whatever is left to do in
+	// it, and a render lasts at least as many wavefront steps as its longest chain of path segments,
+	// so a small job (a rank's share of a frame split over 8 GPUs) is fastest with a pool of about one
+	// slot per stream that needs rays (dragon 1080p x 1024 spp in streams of 8 samples: 32 M such
+	// streams, a ninth of the frame's), up to the 16 Mi that serve the whole frame best.  Measured, one
+	// eighth of that frame: 27.5 / 24.7 / 23.5 / 24.9 / 37 ms with 16 / 8 / 4 / 2 / 1 Mi slots; a quarter:
+	// 43.3 / 42.4 / 42.6 / 47.7 ms with 16 / 8 / 4 / 2 Mi.
+	uint64_t group_blocks = max_group_blocks;
+	if (p->slots <= 0) {
+		const uint64_t pass_runs = (std::min<uint64_t>(n_blocks, pass_blocks) + run_blocks - 1) / run_blocks;
+		const uint64_t listed_streams = (uint64_t)n_listed * (64 / lane_blocks) * pass_runs;
+		const uint64_t want = std::max<uint64_t>(listed_streams, (uint64_t)1 << 20);
+		group_blocks = std::max<uint64_t>(1, std::min<uint64_t>(max_group_blocks, (want / 64 + groups * waves_per_block - 1) / (groups * waves_per_block)));
+	}
+	const uint32_t group_slots = (uint32_t)(group_blocks * 256);
+	const uint32_t n_slots = group_slots * (uint32_t)groups;
+	base.n_slots = group_slots;
+	// per group: 2 parities x kRayKinds kinds x kShards sub-queues, each able to take
+	// everything its share of the group's workgroups can append in one launch
+	const uint32_t shard_cap = (uint32_t)((group_blocks + kShards - 1) / kShards) * 256;
+	const size_t group_queue = (size_t)2 * kRayKinds * kShards * shard_cap;
+	const size_t group_bounce = (size_t)2 * kShards * shard_cap * 2;      // quads
+	// one RenderArgs and one stream per slot group
+	std::vector<RenderArgs> ga((size_t)groups, base);
+	std::vector<hipStream_t> gs((size_t)groups);
+	for (int g = 0; g < groups; g++) {
+		const size_t off = (size_t)g * group_slots;
+		RenderArgs &a = ga[g];
+		a.ray0 = ctx->ray0.as<float4>() + off;
+		a.ray1 = ctx->ray1.as<float4>() + off;
+		a.hit = ctx->hit.as<float4>() + off;
+		a.thr = ctx->thr.as<float4>() + off;
+		a.col = ctx->col.as<float4>() + off;
+		a.rng = ctx->rng.as<uint32_t>() + off;
+		a.acc = ctx->acc.as<float4>() + off;
+		a.meta = ctx->meta.as<uint4>() + off;
+		if (base.hint)
+			a.hint = base.hint + off;
+		a.shadow = ctx->shadow.as<float4>() ? ctx->shadow.as<float4>() + 3 * (size_t)g * kShards * shard_cap : nullptr;
+		a.q_ray = ctx->q_ray.as<uint32_t>() + (size_t)g * group_queue;
+		a.q_bounce = ctx->q_bounce.as<float4>() + (size_t)g * group_bounce;
+		a.shard_cap = shard_cap;
+		a.grid_cap = shard_cap;
+		a.cnt = ctx->counters.as<Counters>() + g;
+		gs[g] = g == 0 ? ctx->stream : ctx->extra[g - 1];
+	}
+
 	HIP_TRY_R(hipEventRecord(ev_mid, s));
 	for (int g = 1; g < groups; g++)
 		HIP_TRY_R(hipStreamWaitEvent(gs[g], ev_mid, 0));

@@ -172,9 +172,9 @@ void launch_batch_occluded(hipStream_t s, const TreeRef &tree, const float *rays
                            uint8_t *out, int depth, const uint32_t *order = nullptr);
 // sort_rays.hip: the tracing order of a big batch (by origin cell and direction octant)
 size_t ray_order_temp_bytes(uint32_t n);
-constexpr uint32_t kDescentCounters = 64;      // words at `descents`, whose sum is the number of out-of-order rays
+constexpr uint32_t kDescentCounters = 64;      // counters at descents[k * stride], whose sum is the number of out-of-order rays
 void launch_ray_keys(hipStream_t s, const float *rays, uint32_t n, const float box_lo[3], const float box_hi[3], uint32_t *keys,
-                     uint32_t *index, uint32_t *descents);
+                     uint32_t *index, uint32_t *descents, uint32_t stride = 1);
 hipError_t launch_ray_sort(hipStream_t s, uint32_t n, uint32_t *keys, uint32_t *keys_sorted, uint32_t *index, uint32_t *order,
                            void *temp, size_t temp_bytes);
 }  // namespace rta

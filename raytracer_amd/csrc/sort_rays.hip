@@ -42,13 +42,19 @@ __device__ inline uint32_t ray_key(const float *r, const float lo_x, const float
 	return (cell << 3) | octant;
 }
 
-// keys[i], index[i] = i, and in descents[0..kDescentCounters) together the number of rays whose key is below
-// the key of the ray before them (0 for a batch that is in order already).  Several counters, because a
-// million waves adding to one word queue up behind one another (12 ms for 64 Mi incoherent rays).
+// keys[i], index[i] = i, and in descents[k * stride], k < kDescentCounters, together the number of rays whose
+// key is below the key of the ray before them (0 for a batch that is in order already).  One atomic per
+// workgroup, spread over counters that a caller with room for them keeps in different 128-byte lines: atomics on
+// one line are served one after the other by its L2 channel (a million of them, one per wave of 64 Mi
+// incoherent rays on 64 neighbouring words, took 5 ms).
 __global__ __launch_bounds__(kBlock) void k_ray_keys(const float *rays, const uint32_t n, const float lo_x, const float lo_y,
                                                     const float lo_z, const float sx, const float sy, const float sz,
-                                                    uint32_t *keys, uint32_t *index, uint32_t *descents)
+                                                    uint32_t *keys, uint32_t *index, uint32_t *descents, const uint32_t stride)
 {
+	__shared__ uint32_t block_descents;
+	if (threadIdx.x == 0)
+		block_descents = 0;
+	__syncthreads();
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
 	bool descent = false;
 	if (i < n) {
@@ -59,7 +65,10 @@ __global__ __launch_bounds__(kBlock) void k_ray_keys(const float *rays, const ui
 	}
 	const unsigned long long votes = __ballot(descent);
 	if ((threadIdx.x & 63) == 0 && votes)
-		atomicAdd(descents + (blockIdx.x * (kBlock / 64) + threadIdx.x / 64) % kDescentCounters, (uint32_t)__popcll(votes));
+		atomicAdd(&block_descents, (uint32_t)__popcll(votes));
+	__syncthreads();
+	if (threadIdx.x == 0 && block_descents)
+		atomicAdd(descents + (size_t)(blockIdx.x % kDescentCounters) * stride, block_descents);
 }
 
 }  // namespace
@@ -73,16 +82,16 @@ size_t ray_order_temp_bytes(uint32_t n)
 }
 
 void launch_ray_keys(hipStream_t s, const float *rays, uint32_t n, const float box_lo[3], const float box_hi[3], uint32_t *keys,
-                     uint32_t *index, uint32_t *descents)
+                     uint32_t *index, uint32_t *descents, uint32_t stride)
 {
 	float scale[3];
 	for (int k = 0; k < 3; k++) {
 		const float extent = box_hi[k] - box_lo[k];
 		scale[k] = extent > 0.f ? 128.f / extent : 0.f;
 	}
-	(void)hipMemsetAsync(descents, 0, kDescentCounters * sizeof(uint32_t), s);
+	(void)hipMemsetAsync(descents, 0, ((size_t)(kDescentCounters - 1) * stride + 1) * sizeof(uint32_t), s);
 	hipLaunchKernelGGL(k_ray_keys, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, rays, n, box_lo[0], box_lo[1], box_lo[2],
-	                   scale[0], scale[1], scale[2], keys, index, descents);
+	                   scale[0], scale[1], scale[2], keys, index, descents, stride);
 }
 
 hipError_t launch_ray_sort(hipStream_t s, uint32_t n, uint32_t *keys, uint32_t *keys_sorted, uint32_t *index, uint32_t *order,

@@ -25,6 +25,14 @@ int rta_debug_arith(rta_context *ctx, int op, const float *x, const float *y, fl
  * a census instead of hits); all but 0 take device pointers only. */
 int rta_debug_trace_variant(rta_context *ctx, int variant, const float *rays, int64_t n, rta_hit *hits, int mem);
 
+/* Test hook: the device layouts of the uploaded scene, copied to the host.  which: 0 pair records, 1 primitive
+ * records, 2 shading records, 3 the reference's node records, 4 the wide tree's nodes, 5 the leaf boxes;
+ * 6: sixteen 32-bit words of scalars (pair count, root reference, tame, box known, the box's six floats, stack
+ * depth, wide tree present, its depth, index mask, reach, span).  *bytes receives the size; out may be NULL to
+ * ask for it, else cap must be at least that.  Used to compare the two upload paths (host-built and
+ * device-built layouts). */
+int rta_debug_scene_buffer(rta_context *ctx, int which, void *out, size_t cap, size_t *bytes);
+
 #ifdef __cplusplus
 }
 #endif

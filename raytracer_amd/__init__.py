@@ -126,6 +126,7 @@ _SIGNATURES = {
 _PROBE_SIGNATURES = {
     "rta_debug_arith": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "rta_debug_trace_variant": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]),
+    "rta_debug_scene_buffer": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
 }
 
 _lib = None
@@ -458,6 +459,16 @@ class Context:
 
     def resolve_device(self, accum_ptr, width, height, samples, exposure, bgr_ptr):
         self._check(lib().rta_resolve(self._h, accum_ptr, width, height, samples, exposure, bgr_ptr, MEM_DEVICE))
+
+    def scene_buffer(self, which):
+        """A device layout of the uploaded scene as bytes (rta_debug_scene_buffer): 0 pairs, 1 primitives,
+        2 shading records, 3 reference nodes, 4 wide nodes, 5 leaf boxes, 6 scalars."""
+        n = C.c_size_t(0)
+        self._check(probe_lib().rta_debug_scene_buffer(self._h, which, None, 0, C.byref(n)))
+        out = np.empty(n.value, np.uint8)
+        if n.value:
+            self._check(probe_lib().rta_debug_scene_buffer(self._h, which, out.ctypes.data, n.value, C.byref(n)))
+        return out
 
     def arith(self, op, x, y=None):
         ops = {"div": 0, "sqrt": 1, "sin": 2, "cos": 3, "log": 4, "pow": 5, "fma": 6, "muladd": 7, "quot": 8}

@@ -17,6 +17,7 @@
 #include "context.hpp"
 #include "host_scene.hpp"
 #include "kernels.hpp"
+#include "upload_device.hpp"
 #include "wide_tree.hpp"
 
 namespace rta {
@@ -179,6 +180,30 @@ inline float as_float(uint32_t u)
 	return f;
 }
 
+// The material and light records (a handful; shared by both upload paths).  The description's
+// index ranges have been checked.
+void small_records(const rta_scene_desc &d, std::vector<float4> &mats, std::vector<float4> &lights)
+{
+	mats.resize((size_t)d.n_materials * 2);
+	for (int32_t m = 0; m < d.n_materials; m++) {
+		const float *s = d.materials + (size_t)m * 6;
+		mats[(size_t)m * 2 + 0] = make_float4(s[0], s[1], s[2], s[3]);
+		mats[(size_t)m * 2 + 1] = make_float4(s[4], s[5], 0, 0);
+	}
+	lights.assign(std::max<size_t>((size_t)d.n_lights, 1) * 7, make_float4(0, 0, 0, 0));
+	for (int32_t l = 0; l < d.n_lights; l++) {
+		int32_t p = d.light_prim[l];
+		const float *c = d.light_color + (size_t)l * 3;
+		const float *g = d.prim_geom + (size_t)p * 9, *nn = d.prim_normals + (size_t)p * 9;
+		float4 *L = &lights[(size_t)l * 7];
+		L[0] = make_float4(c[0], c[1], c[2], as_float((uint32_t)p));
+		for (int q = 0; q < 3; q++) {
+			L[1 + q] = make_float4(g[q * 3], g[q * 3 + 1], g[q * 3 + 2], 0);
+			L[4 + q] = make_float4(nn[q * 3], nn[q * 3 + 1], nn[q * 3 + 2], 0);
+		}
+	}
+}
+
 // Checks everything the kernels take for granted and builds their layouts.
 // Returns an empty string on success, else what is wrong.
 std::string flatten(const rta_scene_desc &d, Flattened &out)
@@ -328,24 +353,7 @@ std::string flatten(const rta_scene_desc &d, Flattened &out)
 		out.shade[(size_t)k * 3 + 1] = make_float4(nn[3], nn[4], nn[5], as_float((uint32_t)d.prim_light[k]));
 		out.shade[(size_t)k * 3 + 2] = make_float4(nn[6], nn[7], nn[8], as_float((uint32_t)d.prim_type[k]));
 	}
-	out.mats.resize((size_t)d.n_materials * 2);
-	for (int32_t m = 0; m < d.n_materials; m++) {
-		const float *s = d.materials + (size_t)m * 6;
-		out.mats[(size_t)m * 2 + 0] = make_float4(s[0], s[1], s[2], s[3]);
-		out.mats[(size_t)m * 2 + 1] = make_float4(s[4], s[5], 0, 0);
-	}
-	out.lights.resize(std::max<size_t>((size_t)d.n_lights, 1) * 7, make_float4(0, 0, 0, 0));
-	for (int32_t l = 0; l < d.n_lights; l++) {
-		int32_t p = d.light_prim[l];
-		const float *c = d.light_color + (size_t)l * 3;
-		const float *g = d.prim_geom + (size_t)p * 9, *nn = d.prim_normals + (size_t)p * 9;
-		float4 *L = &out.lights[(size_t)l * 7];
-		L[0] = make_float4(c[0], c[1], c[2], as_float((uint32_t)p));
-		for (int q = 0; q < 3; q++) {
-			L[1 + q] = make_float4(g[q * 3], g[q * 3 + 1], g[q * 3 + 2], 0);
-			L[4 + q] = make_float4(nn[q * 3], nn[q * 3 + 1], nn[q * 3 + 2], 0);
-		}
-	}
+	small_records(d, out.mats, out.lights);
 	return "";
 }
 
@@ -440,14 +448,36 @@ int rta_upload_scene(rta_context *ctx, const rta_scene_desc *desc)
 		return RTA_E_INVALID;
 	if (!desc)
 		return ctx->fail(RTA_E_INVALID, "null scene description");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	int rc;
+	if (upload_goes_to_device(*desc)) {
+		// large scenes: checks, layouts and the wide tree by kernels (upload_device.hip); what that path
+		// does not handle, an invalid description included, comes back here
+		ctx->have_scene = false;
+		ctx->prepared.valid = false;
+		rc = upload_scene_on_device(ctx, *desc);
+		if (rc < 0)
+			return rc;
+		if (rc == kUploadDone) {
+			std::vector<float4> mats, lights;
+			small_records(*desc, mats, lights);
+			if ((rc = upload_vec(ctx, ctx->materials, mats)) || (rc = upload_vec(ctx, ctx->lights, lights)))
+				return rc;
+			HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // the staging vectors die with this call
+			ctx->have_soa = false;
+			ctx->n_prims = desc->n_prims;
+			ctx->n_nodes = desc->n_nodes;
+			ctx->n_lights = desc->n_lights;
+			ctx->have_scene = true;
+			return RTA_OK;
+		}
+	}
 	Flattened f;
 	std::string problem = flatten(*desc, f);
 	if (!problem.empty())
 		return ctx->fail(f.over_limit ? RTA_E_LIMIT : RTA_E_INVALID, "invalid scene: " + problem);
-	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	ctx->have_scene = false;
 	ctx->prepared.valid = false;
-	int rc;
 	if ((rc = upload_vec(ctx, ctx->pairs, f.pairs)) || (rc = upload_vec(ctx, ctx->prims, f.prims)) ||
 	    (rc = upload_vec(ctx, ctx->shade_prims, f.shade)) || (rc = upload_vec(ctx, ctx->materials, f.mats)) ||
 	    (rc = upload_vec(ctx, ctx->lights, f.lights)) || (rc = upload_vec(ctx, ctx->ref_nodes, f.ref_nodes)))
@@ -463,6 +493,7 @@ int rta_upload_scene(rta_context *ctx, const rta_scene_desc *desc)
 		ctx->wide_reach = wide.reach;
 		ctx->wide_depth = wide.depth;
 		ctx->wide_index_mask = wide.index_mask;
+		ctx->wide_n_nodes = wide.n_nodes;
 		ctx->wide_span = wide.span;
 		ctx->n_loose = (uint32_t)wide.spheres.size();
 		if (!wide.spheres.empty() && (rc = upload_vec(ctx, ctx->loose, wide.spheres)))
@@ -481,6 +512,7 @@ int rta_upload_scene(rta_context *ctx, const rta_scene_desc *desc)
 	ctx->tame = f.tame;
 	ctx->stack_depth = f.depth;
 	ctx->n_prims = desc->n_prims;
+	ctx->n_nodes = desc->n_nodes;
 	ctx->n_lights = desc->n_lights;
 	ctx->have_scene = true;
 	return RTA_OK;

@@ -70,7 +70,8 @@ struct rta_context {
 	bool box_known = false;      // `box` is the box around the root's two children
 	float box[6] = {0, 0, 0, 0, 0, 0};
 	int stack_depth = 1;
-	int32_t n_prims = 0, n_lights = 0;
+	int32_t n_prims = 0, n_lights = 0, n_nodes = 0;
+	uint32_t wide_n_nodes = 0;
 
 	// wavefront workspace
 	rta::DeviceBuffer ray0, ray1, hit, thr, col, rng, acc, meta, hint, q_ray, q_bounce, shadow, partial, pixels, frame, bgr, counters;

@@ -3,6 +3,7 @@
 // variants (variants.hip) and a device arithmetic probe.  Declared in
 // include/raytracer_amd_probe.h.
 #include <cstdint>
+#include <cstring>
 
 #include "context.hpp"
 #include "probe.hpp"
@@ -65,6 +66,51 @@ int rta_debug_arith(rta_context *ctx, int op, const float *x, const float *y, fl
 	HIP_TRY(ctx, hipGetLastError());
 	HIP_TRY(ctx, hipMemcpyAsync(out, ctx->io_c.ptr, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return RTA_OK;
+}
+
+int rta_debug_scene_buffer(rta_context *ctx, int which, void *out, size_t cap, size_t *bytes)
+{
+	if (!ctx || !bytes)
+		return RTA_E_INVALID;
+	if (!ctx->have_scene)
+		return ctx->fail(RTA_E_NO_SCENE, "no scene uploaded");
+	uint32_t scalars[16] = {0};
+	const void *src = nullptr;
+	size_t n = 0;
+	switch (which) {
+	case 0: src = ctx->pairs.ptr, n = (size_t)ctx->n_pairs * 64; break;
+	case 1: src = ctx->prims.ptr, n = (size_t)ctx->n_prims * 16 * kPrimQuads; break;
+	case 2: src = ctx->shade_prims.ptr, n = (size_t)ctx->n_prims * 48; break;
+	case 3: src = ctx->ref_nodes.ptr, n = (size_t)ctx->n_nodes * 32; break;
+	case 4: src = ctx->wide_nodes.ptr, n = ctx->have_wide ? (size_t)ctx->wide_n_nodes * 64 : 0; break;
+	case 5: src = ctx->leaf_boxes.ptr, n = ctx->have_wide ? (size_t)ctx->n_prims * 32 : 0; break;
+	case 6: {
+		scalars[0] = ctx->n_pairs, scalars[1] = ctx->root_ref, scalars[2] = ctx->tame, scalars[3] = ctx->box_known;
+		memcpy(scalars + 4, ctx->box, 24);
+		scalars[10] = (uint32_t)ctx->stack_depth, scalars[11] = ctx->have_wide;
+		if (ctx->have_wide) {
+			scalars[12] = (uint32_t)ctx->wide_depth, scalars[13] = ctx->wide_index_mask;
+			memcpy(scalars + 14, &ctx->wide_reach, 4);
+			memcpy(scalars + 15, &ctx->wide_span, 4);
+		}
+		*bytes = sizeof scalars;
+		if (out) {
+			if (cap < sizeof scalars)
+				return ctx->fail(RTA_E_INVALID, "buffer too small");
+			memcpy(out, scalars, sizeof scalars);
+		}
+		return RTA_OK;
+	}
+	default: return ctx->fail(RTA_E_INVALID, "no such buffer");
+	}
+	*bytes = n;
+	if (!out || n == 0)
+		return RTA_OK;
+	if (cap < n)
+		return ctx->fail(RTA_E_INVALID, "buffer too small");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	HIP_TRY(ctx, hipMemcpy(out, src, n, hipMemcpyDeviceToHost));
 	return RTA_OK;
 }
 

@@ -20,7 +20,9 @@ int rta_debug_arith(rta_context *ctx, int op, const float *x, const float *y, fl
  * design decision changed - 1 traversal stack in private memory, 2 division-based
  * box test for every ray, 3 the reference's 32-byte node array with a node-number
  * stack, 4 two nested loops per ray instead of one, 5 struct-of-arrays nodes;
- * 100 and up: scheduling and
+ * 20 the certified walk over the wide tree followed by the exact traversal of the
+ * rays it leaves in doubt, 21 the walk alone: a ray in doubt comes back with
+ * prim = -2, every other answer is one the walk has proven; 100 and up: scheduling and
  * occupancy experiments listed in csrc/variants.hip.  Same results (100 returns
  * a census instead of hits); all but 0 take device pointers only. */
 int rta_debug_trace_variant(rta_context *ctx, int variant, const float *rays, int64_t n, rta_hit *hits, int mem);

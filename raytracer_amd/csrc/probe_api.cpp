@@ -23,13 +23,13 @@ int rta_debug_trace_variant(rta_context *ctx, int variant, const float *rays, in
 		return rta_internal_trace_closest(ctx, rays, n, hits, mem, 0);
 	if (!ctx->have_scene)
 		return ctx->fail(RTA_E_NO_SCENE, "no scene uploaded");
-	if (variant == 20) {
+	if (variant == 20 || variant == 21) {
 		if (!ctx->have_wide)
 			return ctx->fail(RTA_E_INVALID, "the scene has no wide tree");
 		if (n <= 0 || !rays || !hits || mem != RTA_MEM_DEVICE)
-			return ctx->fail(RTA_E_INVALID, "variant 20 takes device-resident ray batches");
+			return ctx->fail(RTA_E_INVALID, "variants 20 and 21 take device-resident ray batches");
 		HIP_TRY(ctx, hipSetDevice(ctx->device));
-		launch_wide_batch(ctx->stream, tree_of(ctx), rays, (uint64_t)n, hits, ctx->stack_depth);
+		launch_wide_batch(ctx->stream, tree_of(ctx), rays, (uint64_t)n, hits, ctx->stack_depth, variant == 20);
 		HIP_TRY(ctx, hipGetLastError());
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 		return RTA_OK;

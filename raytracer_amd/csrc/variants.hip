@@ -427,7 +427,7 @@ static int env_int(const char *name, int fallback)
 	return v && *v ? atoi(v) : fallback;
 }
 
-void launch_wide_batch(hipStream_t s, const TreeRef &tree, const float *rays, uint64_t n, rta_hit *hits, int depth)
+void launch_wide_batch(hipStream_t s, const TreeRef &tree, const float *rays, uint64_t n, rta_hit *hits, int depth, bool redo)
 {
 	const int cap = env_int("RTA_WIDE_CAP", 20), rpl = env_int("RTA_WIDE_RPL", 8), refill = env_int("RTA_WIDE_REFILL", 24),
 	          quorum = env_int("RTA_WIDE_QUORUM", 24), wq = env_int("RTA_WIDE_WAITING", 64), count = env_int("RTA_WIDE_COUNT", 0);
@@ -459,8 +459,9 @@ void launch_wide_batch(hipStream_t s, const TreeRef &tree, const float *rays, ui
 		hipLaunchKernelGGL(k_wide_batch<false>, dim3(blocks), dim3(kBlock), lds, s, tree, rays, n, hits, cap, (uint32_t)rpl,
 		                   (uint32_t)refill, (uint32_t)quorum, (uint32_t)wq, (unsigned long long *)nullptr, use_heads, (uint32_t)env_int("RTA_WIDE_CHUNK", 256));
 	}
-	hipLaunchKernelGGL(k_wide_redo, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock),
-	                   (size_t)depth * kBlock * sizeof(uint32_t), s, tree, rays, n, hits, depth);
+	if (redo)
+		hipLaunchKernelGGL(k_wide_redo, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock),
+		                   (size_t)depth * kBlock * sizeof(uint32_t), s, tree, rays, n, hits, depth);
 }
 
 void launch_pairs_to_soa(hipStream_t s, const float4 *pairs, uint32_t n_pairs, float *soa)

@@ -218,6 +218,10 @@ def main():
     ap.add_argument("--rays", type=int, default=0, help="soup10m: rays per batch (default 64 Mi)")
     ap.add_argument("--exact-only", action="store_true",
                     help="every ray through the order-replaying traversal, to price the certified walk")
+    ap.add_argument("--also", default=None,
+                    help="comma-separated workloads to run after the main one, each for 2 steps, condensed under "
+                         "`other_workloads` (default for the default workload on one GPU: cornell1080p,soup10m,dragon4k; "
+                         "'none' switches it off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the extra passes behind `roofline`")
     args = ap.parse_args()
@@ -248,6 +252,19 @@ def main():
 
     env = dict(rank=rank, world=world, local=local, dev=dev, dist=dist, rehearsal=rehearsal)
     line = bench_soup(args, env) if args.workload == "soup10m" else bench_render(args, env)
+    # BASELINE.json's other single-GPU configurations, beside the one the metric is quoted on
+    also = args.also if args.also is not None else ("cornell1080p,soup10m,dragon4k" if args.workload == "dragon1080p" and world == 1
+                                                    and not args.spp else "none")
+    if world == 1 and also != "none":
+        line["other_workloads"] = {}
+        for name in also.split(","):
+            side = argparse.Namespace(**vars(args))
+            side.workload, side.steps, side.warmup, side.no_roofline, side.no_cpu_baseline = name, 2, 1, True, True
+            side.samples_per_stream = side.spp = side.tris = side.rays = 0
+            full = bench_soup(side, env) if name == "soup10m" else bench_render(side, env)
+            keep = ("value", "unit", "ms_per_step", "steps", "warmup", "samples_per_s", "traced_mrays_per_s", "cold_ms_first_step",
+                    "batches", "scene", "config")
+            line["other_workloads"][name] = {k: full[k] for k in keep if k in full}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:

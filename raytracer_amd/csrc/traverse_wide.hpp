@@ -268,15 +268,21 @@ struct WideTraversal {
 	{
 		const uint32_t dmask = 0x7fffffffu & ~tree.wide_index_mask;
 		const uint32_t reach = distance_bits(tree, best * (1.f + 0x1p-20f), dmask);
+		// the nearer of the list's last two entries: a hit there spares the test of the other
 		uint32_t e = stack[lp * STRIDE];
+		if (lp + 1 < cap) {
+			const uint32_t f = stack[(lp + 1) * STRIDE];
+			if ((f & dmask) < (e & dmask)) {
+				stack[(lp + 1) * STRIDE] = e;
+				e = f;
+			}
+		}
 		lp++;
 		if ((e & dmask) > reach) {
-			if (lp >= cap)
-				return;
-			e = stack[lp * STRIDE];
-			lp++;
-			if ((e & dmask) > reach)
-				return;
+			// (the other one is no nearer)
+			if (lp < cap)
+				lp++;
+			return;
 		}
 		const uint32_t i = e & tree.wide_index_mask;
 		if ((int32_t)i == prim)

@@ -14,9 +14,9 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/bench_traced.log" 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace1" -- python3 "$R/bench.py" --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-roofline > "$OUT/bench_traced1.log" 2>&1 || exit 1
-ONE="--steps 1 --warmup 0 --no-cpu-baseline --no-roofline"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --also none > "$OUT/bench_traced.log" 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace1" -- python3 "$R/bench.py" --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-roofline --also none > "$OUT/bench_traced1.log" 2>&1 || exit 1
+ONE="--steps 1 --warmup 0 --no-cpu-baseline --no-roofline --also none"
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$R/bench.py" $ONE > "$OUT/pmc_fetch.log" 2>&1 || exit 2
 timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$R/bench.py" $ONE > "$OUT/pmc_write.log" 2>&1 || exit 3
 timeout -s KILL 240 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_l2" -- python3 "$R/bench.py" $ONE > "$OUT/pmc_l2.log" 2>&1 || exit 4

@@ -98,10 +98,12 @@ def main():
     if not ref:
         print("no PMC runs found")
         return
-    traced = ref["traced_mrays_per_s"] * 1e6 * ref["ms_per_step"] * 1e-3 * ref["steps"]     # traced queries of ONE render
-    samples = ref["samples_per_s"] * ref["ms_per_step"] * 1e-3 * ref["steps"]
+    # every render of a profiled run is counted: the warm-up and timed steps and the cold step after them
+    renders = ref["steps"] + ref["warmup"] + (1 if ref.get("cold_ms_first_step") is not None else 0)
+    traced = ref["traced_mrays_per_s"] * 1e6 * ref["ms_per_step"] * 1e-3 * renders     # traced queries of the profiled run
+    samples = ref["samples_per_s"] * ref["ms_per_step"] * 1e-3 * renders
     out = {"tag": tag, "workload": ref["config"]["workload"], "pmc_runs": pmc_cmd,
-           "traced_queries_per_render": traced, "samples_per_render": samples,
+           "renders_per_profiled_run": renders, "traced_queries_per_run": traced, "samples_per_run": samples,
            "formulas": {
                "hbm_bytes_per_launch": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 / launches (read side doubled: gfx950 FETCH_SIZE "
                                        "tallies 128-B requests at 64 B)",

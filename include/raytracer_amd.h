@@ -210,6 +210,8 @@ typedef struct {
 	int64_t rays;
 	int32_t sorted;               /* the batch was traced in the order of its rays' origins */
 	int32_t walked;               /* the batch went through the walk over the wide tree first */
+	int32_t packets;              /* ... 64 consecutive rays at a time together (a batch whose neighbouring rays travel together) */
+	int32_t reserved;
 	uint64_t retraced_rays;       /* of a walked batch: rays left to the order-replaying traversal */
 	double order_ms;              /* sort keys and radix sort */
 	double walk_ms;               /* the walk's kernel */

@@ -78,7 +78,8 @@ class Stats(C.Structure):
 
 
 class BatchStats(C.Structure):
-    _fields_ = [("rays", C.c_int64), ("sorted", C.c_int32), ("walked", C.c_int32), ("retraced_rays", C.c_uint64),
+    _fields_ = [("rays", C.c_int64), ("sorted", C.c_int32), ("walked", C.c_int32), ("packets", C.c_int32),
+                ("reserved", C.c_int32), ("retraced_rays", C.c_uint64),
                 ("order_ms", C.c_double), ("walk_ms", C.c_double), ("replay_ms", C.c_double),
                 ("walk_node_visits", C.c_uint64), ("walk_tri_tests", C.c_uint64),
                 ("replay_node_visits", C.c_uint64), ("replay_prim_tests", C.c_uint64)]

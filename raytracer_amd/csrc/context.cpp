@@ -544,9 +544,11 @@ static int batch_walk_cap()
 // to the device array of ray numbers, or to null when the batch is traced as it
 // comes: small batches, small trees (the order costs more than it saves) and
 // trees without a known box.
-static int tracing_order(rta_context *ctx, const float *d_rays, int64_t n, const uint32_t *&order)
+// `together`: the batch comes in order and (nearly) all of its waves of 64 consecutive rays travel together.
+static int tracing_order(rta_context *ctx, const float *d_rays, int64_t n, const uint32_t *&order, bool &together)
 {
 	order = nullptr;
+	together = false;
 	const size_t tree_bytes = (size_t)ctx->n_pairs * 64 + (size_t)ctx->n_prims * 16 * kPrimQuads;
 	if (!ctx->box_known || n < (1 << 16) || n >= ((int64_t)1 << 32) || tree_bytes < ((size_t)8 << 20))
 		return RTA_OK;
@@ -562,11 +564,15 @@ static int tracing_order(rta_context *ctx, const float *d_rays, int64_t n, const
 	uint32_t counters[kDescentCounters * kStride];
 	HIP_TRY(ctx, hipMemcpyAsync(counters, descents, sizeof counters, hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-	uint64_t out_of_order = 0;
-	for (uint32_t k = 0; k < kDescentCounters; k++)
+	uint64_t out_of_order = 0, spread_waves = 0;
+	for (uint32_t k = 0; k < kDescentCounters; k++) {
 		out_of_order += counters[k * kStride];
-	if (out_of_order * 16 < count)
+		spread_waves += counters[k * kStride + 1];
+	}
+	if (out_of_order * 16 < count) {
+		together = spread_waves * 64 <= (count + 63) / 64;      // at most one wave in 64 whose rays go apart
 		return RTA_OK;
+	}
 	HIP_TRY(ctx, launch_ray_sort(ctx->stream, count, keys, keys_sorted, index, sorted, base + 4 * each, temp));
 	order = sorted;
 	return RTA_OK;
@@ -606,7 +612,8 @@ int rta_internal_trace_closest(rta_context *ctx, const float *rays, int64_t n, r
 	hipStream_t s = ctx->stream;
 	HIP_TRY(ctx, hipEventRecord(ctx->batch_ev[0], s));
 	const uint32_t *order = nullptr;
-	if (int rc = tracing_order(ctx, d_rays, n, order))
+	bool together = false;
+	if (int rc = tracing_order(ctx, d_rays, n, order, together))
 		return rc;
 	bs.sorted = order != nullptr;
 	static const bool exact_only = getenv("RTA_BATCH_EXACT") != nullptr;      // measurement: price the walk
@@ -635,7 +642,15 @@ int rta_internal_trace_closest(rta_context *ctx, const float *rays, int64_t n, r
 	if (walk && ctx->have_wide && n < ((int64_t)1 << 32) && !exact_only) {
 		// the certified walk answers what it can prove; the rest goes through the replaying traversal
 		uint32_t *list = ctx->doubts.as<uint32_t>(), *count = (uint32_t *)(ctx->doubts.as<char>() + list_bytes);
-		launch_batch_walk(s, tree_of(ctx), d_rays, (uint64_t)n, d_hits, cap, order, list, count, cnt);
+		// neighbouring rays that travel together walk the tree together (RTA_BATCH_PACKETS=0: measurement)
+		// (2: every batch, whatever its rays do - tests)
+		const char *packets_env = getenv("RTA_BATCH_PACKETS");
+		const int packets_mode = packets_env ? atoi(packets_env) : 1;
+		if ((together && !order && packets_mode == 1) || packets_mode == 2) {
+			launch_batch_packet(s, tree_of(ctx), d_rays, (uint64_t)n, d_hits, list, count, cnt);
+			bs.packets = 1;
+		} else
+			launch_batch_walk(s, tree_of(ctx), d_rays, (uint64_t)n, d_hits, cap, order, list, count, cnt);
 		HIP_TRY(ctx, hipGetLastError());
 		HIP_TRY(ctx, hipEventRecord(ctx->batch_ev[2], s));
 		uint32_t in_doubt = 0;
@@ -700,7 +715,8 @@ int rta_trace_occluded(rta_context *ctx, const float *rays, const float *tmax, i
 		d_out = ctx->io_c.as<uint8_t>();
 	}
 	const uint32_t *order = nullptr;
-	if (int rc = tracing_order(ctx, d_rays, n, order))
+	bool together = false;
+	if (int rc = tracing_order(ctx, d_rays, n, order, together))
 		return rc;
 	static const bool exact_only = getenv("RTA_BATCH_EXACT") != nullptr;      // measurement: price the walk
 	if (ctx->have_wide && n < ((int64_t)1 << 32) && !exact_only)
@@ -960,15 +976,19 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		HIP_TRY(ctx, ctx->sky_map.reserve(frame_px * 4));
 		base.sky_map = ctx->sky_map.as<const float>();
 	}
-	// long leaves (4 primitives and more on average): see traverse_leafwise
-	base.leafwise = (uint64_t)ctx->n_prims >= 4 * ((uint64_t)ctx->n_pairs + 1) ? 1u : 0u;
 	// Bounce rays take the certified walk over the wide tree where the scene has one (triangles
 	// only, short leaves); 20 LDS entries per lane keep 8 workgroups on a CU
 	{
 		static const char *sort_lanes = getenv("RTA_SORT_LANES");      // measurement
 		base.sort_lanes = sort_lanes ? (uint32_t)atoi(sort_lanes) : (ctx->n_lights > 0 ? 1u : 0u);
 	}
-	base.wide_cap = (ctx->have_wide && !base.leafwise && !(p->flags & RTA_RENDER_EXACT_ONLY)) ? 20u : 0u;
+	base.wide_cap = (ctx->have_wide && !(p->flags & RTA_RENDER_EXACT_ONLY)) ? 20u : 0u;
+	// Without the walk, long leaves (4 primitives and more on average) are traversed as nested loops: see
+	// traverse_leafwise.  With it they do not matter: the wide tree has a topology of its own, and only the few
+	// rays the walk hands on meet the reference's leaves - which is what makes a mesh standing on a floor of
+	// two large triangles renderable at all (the reference's midpoint split leaves half the mesh in one leaf
+	// with a floor triangle whose box spans the scene: 13 s per 1080p x 256 spp frame replayed, 0.2 s walked).
+	base.leafwise = !base.wide_cap && (uint64_t)ctx->n_prims >= 4 * ((uint64_t)ctx->n_pairs + 1) ? 1u : 0u;
 	// Camera rays join them when the camera (a pinhole) lies within the wide tree's reach; each starts
 	// with the triangle that the slot's last camera ray hit: the same pixel, most often the same triangle
 	{

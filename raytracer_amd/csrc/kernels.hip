@@ -44,6 +44,7 @@
 #include "shading.hpp"
 #include "traverse.hpp"
 #include "traverse_wide.hpp"
+#include "traverse_packet.hpp"
 
 namespace rta {
 
@@ -1260,6 +1261,38 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
 		count_flush(cnt, wc);
 }
 
+// The same batch, 64 consecutive rays at a time through the tree TOGETHER (traverse_packet.hpp): for batches
+// whose neighbouring rays travel together (a camera's).  One packet per wave; no LDS.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_batch_packet(const DeviceTree tree, const float *rays, uint64_t n, rta_hit *hits,
+                                                         uint32_t *doubts, uint32_t *n_doubts, Counters *cnt)
+{
+	const uint64_t number = (uint64_t)blockIdx.x * kBlock + threadIdx.x;      // (a wave's 64 lanes: 64 consecutive rays)
+	const bool mine = number < n;
+	Ray ray = {mk(0, 0, 0), mk(1, 1, 1)};
+	if (mine) {
+		const float *r = rays + (size_t)number * 6;
+		ray = Ray{mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5])};
+	}
+	WorkCount wc = {0, 0, 0};
+	walk_packet<COUNT>(tree, mine, ray, (uint32_t)number, wc, [&](bool finished, uint32_t which, const HitRec &h, bool doubt) {
+		if (finished && !doubt)
+			hits[which] = rta_hit{h.prim, h.t, h.u, h.v};
+		const unsigned long long handed_on = __ballot(finished && doubt);
+		if (handed_on) {
+			uint32_t base = 0;
+			if ((threadIdx.x & 63) == (uint32_t)__builtin_ctzll(handed_on))
+				base = atomicAdd(n_doubts, (uint32_t)__popcll(handed_on));
+			base = (uint32_t)__shfl((int)base, __builtin_ctzll(handed_on));
+			if (finished && doubt)
+				doubts[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(handed_on >> 32),
+				                                        __builtin_amdgcn_mbcnt_lo((uint32_t)handed_on, 0u))] = which;
+		}
+	});
+	if (COUNT)
+		count_flush(cnt, wc);
+}
+
 __global__ __launch_bounds__(kBlock) void k_batch_occluded(const DeviceTree tree, const float *rays, const float *tmax,
                                                            uint64_t n, uint8_t *out, const int depth,
                                                            const uint32_t rays_per_lane, const uint32_t *order)
@@ -1452,6 +1485,16 @@ void launch_batch_walk(hipStream_t s, const TreeRef &tree, const float *rays, ui
 	else
 		hipLaunchKernelGGL(k_batch_walk<false>, grid, dim3(kBlock), stack_bytes(cap), s, tree, rays, n, hits, cap, rays_per_lane,
 		                   order, doubts, n_doubts, cnt);
+}
+
+void launch_batch_packet(hipStream_t s, const TreeRef &tree, const float *rays, uint64_t n, rta_hit *hits, uint32_t *doubts,
+                         uint32_t *n_doubts, Counters *cnt)
+{
+	(void)hipMemsetAsync(n_doubts, 0, sizeof(uint32_t), s);
+	if (cnt)
+		hipLaunchKernelGGL(k_batch_packet<true>, dim3(blocks_for(n)), dim3(kBlock), 0, s, tree, rays, n, hits, doubts, n_doubts, cnt);
+	else
+		hipLaunchKernelGGL(k_batch_packet<false>, dim3(blocks_for(n)), dim3(kBlock), 0, s, tree, rays, n, hits, doubts, n_doubts, cnt);
 }
 
 void launch_batch_occluded_walk(hipStream_t s, const TreeRef &tree, const float *rays, const float *tmax, uint64_t n,

@@ -51,24 +51,38 @@ __global__ __launch_bounds__(kBlock) void k_ray_keys(const float *rays, const ui
                                                     const float lo_z, const float sx, const float sy, const float sz,
                                                     uint32_t *keys, uint32_t *index, uint32_t *descents, const uint32_t stride)
 {
-	__shared__ uint32_t block_descents;
+	__shared__ uint32_t block_descents, block_spread;
 	if (threadIdx.x == 0)
-		block_descents = 0;
+		block_descents = block_spread = 0;
 	__syncthreads();
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-	bool descent = false;
+	bool descent = false, apart = false;
 	if (i < n) {
-		const uint32_t key = ray_key(rays + (size_t)i * 6, lo_x, lo_y, lo_z, sx, sy, sz);
+		const float *r = rays + (size_t)i * 6;
+		const uint32_t key = ray_key(r, lo_x, lo_y, lo_z, sx, sy, sz);
 		keys[i] = key;
 		index[i] = i;
 		descent = i > 0 && key < ray_key(rays + (size_t)(i - 1) * 6, lo_x, lo_y, lo_z, sx, sy, sz);
+		if (stride >= 2) {
+			// does this ray travel with the first ray of its wave?  Directions within 2 degrees (cos^2 = 0.99878), origins
+			// within 2 of the 128 cells per axis that the keys are made of; NaNs count as apart
+			const float *f = rays + (size_t)(i & ~63u) * 6;
+			const float dd = r[3] * f[3] + r[4] * f[4] + r[5] * f[5];
+			const float d2 = r[3] * r[3] + r[4] * r[4] + r[5] * r[5], f2 = f[3] * f[3] + f[4] * f[4] + f[5] * f[5];
+			const float ox = (r[0] - f[0]) * sx, oy = (r[1] - f[1]) * sy, oz = (r[2] - f[2]) * sz;
+			apart = !(dd > 0.f && dd * dd >= 0.99878f * d2 * f2 && ox * ox + oy * oy + oz * oz <= 4.f);
+		}
 	}
-	const unsigned long long votes = __ballot(descent);
+	const unsigned long long votes = __ballot(descent), spread = __ballot(apart);
 	if ((threadIdx.x & 63) == 0 && votes)
 		atomicAdd(&block_descents, (uint32_t)__popcll(votes));
+	if ((threadIdx.x & 63) == 0 && spread)
+		atomicAdd(&block_spread, 1u);
 	__syncthreads();
 	if (threadIdx.x == 0 && block_descents)
 		atomicAdd(descents + (size_t)(blockIdx.x % kDescentCounters) * stride, block_descents);
+	if (threadIdx.x == 0 && block_spread)
+		atomicAdd(descents + (size_t)(blockIdx.x % kDescentCounters) * stride + 1, block_spread);
 }
 
 }  // namespace
@@ -89,7 +103,7 @@ void launch_ray_keys(hipStream_t s, const float *rays, uint32_t n, const float b
 		const float extent = box_hi[k] - box_lo[k];
 		scale[k] = extent > 0.f ? 128.f / extent : 0.f;
 	}
-	(void)hipMemsetAsync(descents, 0, ((size_t)(kDescentCounters - 1) * stride + 1) * sizeof(uint32_t), s);
+	(void)hipMemsetAsync(descents, 0, ((size_t)(kDescentCounters - 1) * stride + (stride >= 2 ? 2 : 1)) * sizeof(uint32_t), s);
 	hipLaunchKernelGGL(k_ray_keys, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, rays, n, box_lo[0], box_lo[1], box_lo[2],
 	                   scale[0], scale[1], scale[2], keys, index, descents, stride);
 }

@@ -276,3 +276,86 @@ def test_large_triangles_get_no_wide_tree(gpu):
     bgr, acc, st = gpu.render_scene(psc, seed=2, samples_per_stream=4)
     assert st["walked_rays"] == 0 and st["rays"] == cn["rays"] > 2 * cn["samples"]
     assert np.array_equal(bits(acc), bits(want_acc)) and np.array_equal(bgr, want_bgr)
+
+
+def test_rays_that_travel_together_walk_the_tree_together(gpu, monkeypatch):
+    """A batch in order whose neighbouring rays travel together (a camera's pixels) takes the wide tree 64 rays at
+    a time (csrc/traverse_packet.hpp): same hits as the checker's, bit for bit, and the statistics say which walk
+    ran.  Forced onto rays that do NOT travel together - random ones, and the dragon's, whose tree is too small
+    for the choice to be made at all - the packets are slow but still exact."""
+    import torch
+    from raytracer_amd.synthetic import make_soup
+    tris = make_soup(300_000, seed=13)
+    psc = rta.Scene.from_triangles(tris).build_bvh()
+    osc = orc.Scene.from_triangles(tris).build_bvh()
+    gpu.upload(psc)
+    dev = torch.device("cuda", 0)
+
+    def traced(rr):
+        rt = torch.from_numpy(np.ascontiguousarray(rr, np.float32)).to(dev)
+        ht = torch.zeros((rr.shape[0], 4), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        gpu.trace_closest_device(rt.data_ptr(), rr.shape[0], ht.data_ptr())
+        return ht.cpu().numpy(), gpu.last_batch_stats()
+
+    def checked(rr, got):
+        idx, t, u, v = osc.trace_closest(rr)
+        assert same_hits(got, dict(prim=idx, t=t, u=u, v=v)).all()
+        return idx
+
+    # a pinhole grid from outside, 512 x 512, and the same grid from inside the soup
+    side = 512
+    t = (np.arange(side, dtype=np.float32) + 0.5) / side * 2 - 1
+    y, z = np.meshgrid(t * 0.05, -t * 0.05)       # 64 neighbouring rays within 0.7 degrees
+    d = np.stack([np.ones_like(y), y, z], axis=-1).reshape(-1, 3)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    for origin in ((-3.0, 0.0, 0.0), (0.1, 0.2, -0.3)):
+        rr = np.concatenate([np.broadcast_to(np.float32(origin), d.shape), d], axis=1).astype(np.float32)
+        got, st = traced(rr)
+        assert st["walked"] == 1 and st["packets"] == 1 and st["sorted"] == 0, st
+        idx = checked(rr, got)
+        assert (idx >= 0).mean() > 0.2
+    # rays in order that do not travel together keep the walk of their own
+    rng = np.random.default_rng(5)
+    spread = rr.copy()
+    spread[:, 3:6] = rng.standard_normal((len(rr), 3)).astype(np.float32)
+    got, st = traced(spread)
+    assert st["packets"] == 0, st
+    checked(spread, got)
+    # forced: random rays in packets
+    monkeypatch.setenv("RTA_BATCH_PACKETS", "2")
+    lo, hi = np.full(3, -1.1), np.full(3, 1.1)
+    rr = raygen.random_rays(300_000, lo, hi, seed=77).astype(np.float32)
+    got, st = traced(rr)
+    assert st["packets"] == 1
+    checked(rr, got)
+    # ... and on the dragon: rays inside it, rays outside the walk's reach, zero components, NaN
+    dsc = orc.Scene.load(f"{orc.SCENES}/dragon.txt").build_bvh()
+    gpu.upload(rta.Scene.load(f"{orc.SCENES}/dragon.txt").build_bvh())
+    nodes = dsc.nodes()
+    rr = raygen.random_rays(400_000, nodes["lo"][0] - 0.3, nodes["hi"][0] + 0.3, seed=78).astype(np.float32)
+    rr[::97, 0:3] *= 40.0
+    rr[::101, 4] = 0.0
+    rr[::1009, 3] = np.nan
+    got, st = traced(rr)
+    assert st["packets"] == 1
+    idx, t, u, v = dsc.trace_closest(rr)
+    assert same_hits(got, dict(prim=idx, t=t, u=u, v=v)).all()
+
+
+def test_a_mesh_on_a_floor_of_large_triangles_takes_the_walk(gpu):
+    """dragon.txt standing on two floor triangles eight units wide.  The reference's midpoint splits leave half the
+    mesh in ONE leaf beside a floor triangle (its box spans the scene, every split puts all centroids on one
+    side), which the order-replaying traversal has to plough through; the wide tree has a topology of its own, so
+    the walk answers nearly every ray and only what it hands on meets that leaf.  Same bits as the checker."""
+    text = open(f"{orc.SCENES}/dragon.txt").read().replace("width 400", "width 64").replace("height 400", "height 40").replace("samples 25", "samples 8")
+    text += ("\nmaterial {\n\tcolor [0.6 0.6 0.6]\n\troughness 1\n}\n\ntriangle_mesh {\n\tvertices [ -4 -4 0.27  4 -4 0.27  4 4 0.27   "
+             "-4 -4 0.27  4 4 0.27  -4 4 0.27 ]\n}\n")
+    osc = orc.Scene.parse(text).build_bvh()
+    psc = rta.Scene.parse(text).build_bvh()
+    assert psc.arrays()["node_count"].max() > 1000          # the long leaf
+    gpu.upload(psc)
+    want_bgr, want_acc, cn = osc.render(orc.RNG_STREAM, orc.MATH_PM, seed=3, samples_per_stream=4)
+    bgr, acc, st = gpu.render_scene(psc, seed=3, samples_per_stream=4)
+    assert st["rays"] == cn["rays"] and st["walked_rays"] > 0.9 * st["rays"] and st["retraced_rays"] < 0.05 * st["rays"]
+    assert np.array_equal(bits(acc), bits(want_acc)) and np.array_equal(bgr, want_bgr)

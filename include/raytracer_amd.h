@@ -208,9 +208,9 @@ enum {                                /* OR-ed into the `mem` argument of rta_tr
 
 typedef struct {
 	int64_t rays;
-	int32_t sorted;               /* the batch was traced in the order of its rays' origins */
+	int32_t sorted;               /* the batch was traced in an order of its own making: of its rays' origins, or (packets) directions */
 	int32_t walked;               /* the batch went through the walk over the wide tree first */
-	int32_t packets;              /* ... 64 consecutive rays at a time together (a batch whose neighbouring rays travel together) */
+	int32_t packets;              /* ... 64 rays at a time together (a pinhole camera's batch: one origin, neighbours travel together) */
 	int32_t reserved;
 	uint64_t retraced_rays;       /* of a walked batch: rays left to the order-replaying traversal */
 	double order_ms;              /* sort keys and radix sort */

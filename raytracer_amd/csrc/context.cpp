@@ -544,11 +544,18 @@ static int batch_walk_cap()
 // to the device array of ray numbers, or to null when the batch is traced as it
 // comes: small batches, small trees (the order costs more than it saves) and
 // trees without a known box.
-// `together`: the batch comes in order and (nearly) all of its waves of 64 consecutive rays travel together.
-static int tracing_order(rta_context *ctx, const float *d_rays, int64_t n, const uint32_t *&order, bool &together)
+// `packets`: the batch is a pinhole camera's - in order, 64 consecutive rays travelling together, all from one
+// point - and `order` lists its rays in compact patches of neighbouring directions, for the walk by packets.
+static int packets_mode(const rta_context *ctx)
+{
+	const char *v = getenv("RTA_BATCH_PACKETS");      // measurement and tests: 0 never, 2 every closest-hit batch
+	return ctx->have_wide ? (v ? atoi(v) : 1) : 0;
+}
+
+static int tracing_order(rta_context *ctx, const float *d_rays, int64_t n, const uint32_t *&order, bool &packets, bool closest)
 {
 	order = nullptr;
-	together = false;
+	packets = false;
 	const size_t tree_bytes = (size_t)ctx->n_pairs * 64 + (size_t)ctx->n_prims * 16 * kPrimQuads;
 	if (!ctx->box_known || n < (1 << 16) || n >= ((int64_t)1 << 32) || tree_bytes < ((size_t)8 << 20))
 		return RTA_OK;
@@ -559,18 +566,28 @@ static int tracing_order(rta_context *ctx, const float *d_rays, int64_t n, const
 	char *base = ctx->ray_order.as<char>();
 	uint32_t *keys = (uint32_t *)base, *keys_sorted = (uint32_t *)(base + each), *index = (uint32_t *)(base + 2 * each),
 	         *sorted = (uint32_t *)(base + 3 * each), *descents = (uint32_t *)(base + 4 * each + temp);
-	launch_ray_keys(ctx->stream, d_rays, count, ctx->box, ctx->box + 3, keys, index, descents, kStride);
-	// a batch that comes in order (a camera's rays, say) is not sorted again
+	// (the direction keys go where the origin sort would put its sorted keys: only one of the two sorts runs)
+	const int mode = closest ? packets_mode(ctx) : 0;
+	launch_ray_keys(ctx->stream, d_rays, count, ctx->box, ctx->box + 3, keys, index, descents, kStride, mode ? keys_sorted : nullptr);
+	// a batch that comes in order (a camera's rays, say) is not sorted by its origins
 	uint32_t counters[kDescentCounters * kStride];
 	HIP_TRY(ctx, hipMemcpyAsync(counters, descents, sizeof counters, hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-	uint64_t out_of_order = 0, spread_waves = 0;
+	uint64_t out_of_order = 0, spread_waves = 0, elsewhere_waves = 0;
 	for (uint32_t k = 0; k < kDescentCounters; k++) {
 		out_of_order += counters[k * kStride];
 		spread_waves += counters[k * kStride + 1];
+		elsewhere_waves += counters[k * kStride + 2];
 	}
 	if (out_of_order * 16 < count) {
-		together = spread_waves * 64 <= (count + 63) / 64;      // at most one wave in 64 whose rays go apart
+		// At most one wave in 64 whose rays go apart, and one origin: the rays walk the tree 64 at a time, in
+		// the order of their directions (a scan line's 64 pixels are a strip; 64 neighbours in that order a patch:
+		// 59 instead of 95 node records per packet on the 10 M-triangle soup).
+		if (mode && spread_waves * 64 <= (count + 63) / 64 && elsewhere_waves == 0) {
+			HIP_TRY(ctx, launch_ray_sort(ctx->stream, count, keys_sorted, keys, index, sorted, base + 4 * each, temp, true));
+			order = sorted;
+			packets = true;
+		}
 		return RTA_OK;
 	}
 	HIP_TRY(ctx, launch_ray_sort(ctx->stream, count, keys, keys_sorted, index, sorted, base + 4 * each, temp));
@@ -612,9 +629,11 @@ int rta_internal_trace_closest(rta_context *ctx, const float *rays, int64_t n, r
 	hipStream_t s = ctx->stream;
 	HIP_TRY(ctx, hipEventRecord(ctx->batch_ev[0], s));
 	const uint32_t *order = nullptr;
-	bool together = false;
-	if (int rc = tracing_order(ctx, d_rays, n, order, together))
+	bool packets = false;
+	if (int rc = tracing_order(ctx, d_rays, n, order, packets, true))
 		return rc;
+	if (packets_mode(ctx) == 2)
+		packets = true;           // (forced: whatever order the batch is traced in, 64 of its rays at a time)
 	bs.sorted = order != nullptr;
 	static const bool exact_only = getenv("RTA_BATCH_EXACT") != nullptr;      // measurement: price the walk
 	static const int cap = batch_walk_cap();
@@ -642,12 +661,8 @@ int rta_internal_trace_closest(rta_context *ctx, const float *rays, int64_t n, r
 	if (walk && ctx->have_wide && n < ((int64_t)1 << 32) && !exact_only) {
 		// the certified walk answers what it can prove; the rest goes through the replaying traversal
 		uint32_t *list = ctx->doubts.as<uint32_t>(), *count = (uint32_t *)(ctx->doubts.as<char>() + list_bytes);
-		// neighbouring rays that travel together walk the tree together (RTA_BATCH_PACKETS=0: measurement)
-		// (2: every batch, whatever its rays do - tests)
-		const char *packets_env = getenv("RTA_BATCH_PACKETS");
-		const int packets_mode = packets_env ? atoi(packets_env) : 1;
-		if ((together && !order && packets_mode == 1) || packets_mode == 2) {
-			launch_batch_packet(s, tree_of(ctx), d_rays, (uint64_t)n, d_hits, list, count, cnt);
+		if (packets) {
+			launch_batch_packet(s, tree_of(ctx), d_rays, (uint64_t)n, d_hits, order, list, count, cnt);
 			bs.packets = 1;
 		} else
 			launch_batch_walk(s, tree_of(ctx), d_rays, (uint64_t)n, d_hits, cap, order, list, count, cnt);
@@ -715,8 +730,8 @@ int rta_trace_occluded(rta_context *ctx, const float *rays, const float *tmax, i
 		d_out = ctx->io_c.as<uint8_t>();
 	}
 	const uint32_t *order = nullptr;
-	bool together = false;
-	if (int rc = tracing_order(ctx, d_rays, n, order, together))
+	bool packets = false;
+	if (int rc = tracing_order(ctx, d_rays, n, order, packets, false))
 		return rc;
 	static const bool exact_only = getenv("RTA_BATCH_EXACT") != nullptr;      // measurement: price the walk
 	if (ctx->have_wide && n < ((int64_t)1 << 32) && !exact_only)

@@ -1265,10 +1265,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
 // whose neighbouring rays travel together (a camera's).  One packet per wave; no LDS.
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_batch_packet(const DeviceTree tree, const float *rays, uint64_t n, rta_hit *hits,
-                                                         uint32_t *doubts, uint32_t *n_doubts, Counters *cnt)
+                                                         const uint32_t *order, uint32_t *doubts, uint32_t *n_doubts, Counters *cnt)
 {
-	const uint64_t number = (uint64_t)blockIdx.x * kBlock + threadIdx.x;      // (a wave's 64 lanes: 64 consecutive rays)
-	const bool mine = number < n;
+	// a wave's 64 lanes: 64 consecutive rays of the batch, or of the tracing order
+	const uint64_t place = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+	const bool mine = place < n;
+	const uint64_t number = mine && order ? order[place] : place;
 	Ray ray = {mk(0, 0, 0), mk(1, 1, 1)};
 	if (mine) {
 		const float *r = rays + (size_t)number * 6;
@@ -1487,14 +1489,14 @@ void launch_batch_walk(hipStream_t s, const TreeRef &tree, const float *rays, ui
 		                   order, doubts, n_doubts, cnt);
 }
 
-void launch_batch_packet(hipStream_t s, const TreeRef &tree, const float *rays, uint64_t n, rta_hit *hits, uint32_t *doubts,
-                         uint32_t *n_doubts, Counters *cnt)
+void launch_batch_packet(hipStream_t s, const TreeRef &tree, const float *rays, uint64_t n, rta_hit *hits, const uint32_t *order,
+                         uint32_t *doubts, uint32_t *n_doubts, Counters *cnt)
 {
 	(void)hipMemsetAsync(n_doubts, 0, sizeof(uint32_t), s);
 	if (cnt)
-		hipLaunchKernelGGL(k_batch_packet<true>, dim3(blocks_for(n)), dim3(kBlock), 0, s, tree, rays, n, hits, doubts, n_doubts, cnt);
+		hipLaunchKernelGGL(k_batch_packet<true>, dim3(blocks_for(n)), dim3(kBlock), 0, s, tree, rays, n, hits, order, doubts, n_doubts, cnt);
 	else
-		hipLaunchKernelGGL(k_batch_packet<false>, dim3(blocks_for(n)), dim3(kBlock), 0, s, tree, rays, n, hits, doubts, n_doubts, cnt);
+		hipLaunchKernelGGL(k_batch_packet<false>, dim3(blocks_for(n)), dim3(kBlock), 0, s, tree, rays, n, hits, order, doubts, n_doubts, cnt);
 }
 
 void launch_batch_occluded_walk(hipStream_t s, const TreeRef &tree, const float *rays, const float *tmax, uint64_t n,

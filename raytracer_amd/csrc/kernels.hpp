@@ -165,9 +165,10 @@ void launch_batch_closest(hipStream_t s, const TreeRef &tree, const float *rays,
 // (`cnt`: null, or where the walk adds its node visits and triangle tests)
 void launch_batch_walk(hipStream_t s, const TreeRef &tree, const float *rays, uint64_t n, rta_hit *hits, int cap,
                        const uint32_t *order, uint32_t *doubts, uint32_t *n_doubts, Counters *cnt = nullptr);
-// the same by packets of 64 consecutive rays that walk the tree together (traverse_packet.hpp); n < 2^32
-void launch_batch_packet(hipStream_t s, const TreeRef &tree, const float *rays, uint64_t n, rta_hit *hits, uint32_t *doubts,
-                         uint32_t *n_doubts, Counters *cnt = nullptr);
+// the same by packets of 64 rays that walk the tree together (traverse_packet.hpp): consecutive rays of the batch, or
+// of `order`; n < 2^32
+void launch_batch_packet(hipStream_t s, const TreeRef &tree, const float *rays, uint64_t n, rta_hit *hits, const uint32_t *order,
+                         uint32_t *doubts, uint32_t *n_doubts, Counters *cnt = nullptr);
 // the any-hit walk over the wide tree (n < 2^32); queries it cannot answer for certain are traced exactly in the same launch
 void launch_batch_occluded_walk(hipStream_t s, const TreeRef &tree, const float *rays, const float *tmax, uint64_t n,
                                 uint8_t *out, int cap, int depth, const uint32_t *order);
@@ -176,10 +177,13 @@ void launch_batch_occluded(hipStream_t s, const TreeRef &tree, const float *rays
 // sort_rays.hip: the tracing order of a big batch (by origin cell and direction octant)
 size_t ray_order_temp_bytes(uint32_t n);
 constexpr uint32_t kDescentCounters = 64;      // counters at descents[k * stride], whose sum is the number of out-of-order rays
-// `spread`: with stride >= 2, descents[k * stride + 1] count the waves whose 64 consecutive rays do NOT travel
-// together (directions more than 2 degrees apart, or origins more than 1/64 of the scene's box)
+// With stride >= 3, descents[k * stride + 1] count the waves whose 64 consecutive rays do NOT travel together
+// (directions more than 2 degrees apart, or origins more than 1/64 of the scene's box) and descents[k * stride + 2]
+// the waves with a ray that does not start where the batch's first ray starts.  direction_keys: null, or where the
+// rays' direction keys go (the order that turns a pinhole camera's scan lines into compact patches).
 void launch_ray_keys(hipStream_t s, const float *rays, uint32_t n, const float box_lo[3], const float box_hi[3], uint32_t *keys,
-                     uint32_t *index, uint32_t *descents, uint32_t stride = 1);
+                     uint32_t *index, uint32_t *descents, uint32_t stride = 1, uint32_t *direction_keys = nullptr);
+// all_bits: the keys are direction keys (32 bits), not origin keys (24)
 hipError_t launch_ray_sort(hipStream_t s, uint32_t n, uint32_t *keys, uint32_t *keys_sorted, uint32_t *index, uint32_t *order,
-                           void *temp, size_t temp_bytes);
+                           void *temp, size_t temp_bytes, bool all_bits = false);
 }  // namespace rta

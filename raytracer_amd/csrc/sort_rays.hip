@@ -42,6 +42,33 @@ __device__ inline uint32_t ray_key(const float *r, const float lo_x, const float
 	return (cell << 3) | octant;
 }
 
+// Where a direction points, as a 32-bit Morton code of its octahedral map (16 bits per axis: 3e-5 of the sphere's
+// quarter arc per step): rays from one point sorted by it come out in compact patches of neighbouring directions.
+__device__ inline uint32_t spread2(uint32_t v)      // 16 bits -> every second bit
+{
+	v = (v | (v << 8)) & 0x00ff00ffu;
+	v = (v | (v << 4)) & 0x0f0f0f0fu;
+	v = (v | (v << 2)) & 0x33333333u;
+	v = (v | (v << 1)) & 0x55555555u;
+	return v;
+}
+
+__device__ inline uint32_t direction_key(const float *r)
+{
+	const float x = r[3], y = r[4], z = r[5];
+	const float s = __builtin_fabsf(x) + __builtin_fabsf(y) + __builtin_fabsf(z);
+	float px = x / s, py = y / s;
+	if (z < 0.f) {
+		const float qx = (1.f - __builtin_fabsf(py)) * (px < 0.f ? -1.f : 1.f), qy = (1.f - __builtin_fabsf(px)) * (py < 0.f ? -1.f : 1.f);
+		px = qx;
+		py = qy;
+	}
+	// [-1, 1] -> [0, 65535]; NaN and the like land at 0
+	const float fx = __builtin_fminf(__builtin_fmaxf((px * .5f + .5f) * 65535.f, 0.f), 65535.f);
+	const float fy = __builtin_fminf(__builtin_fmaxf((py * .5f + .5f) * 65535.f, 0.f), 65535.f);
+	return spread2((uint32_t)fx) | (spread2((uint32_t)fy) << 1);
+}
+
 // keys[i], index[i] = i, and in descents[k * stride], k < kDescentCounters, together the number of rays whose
 // key is below the key of the ray before them (0 for a batch that is in order already).  One atomic per
 // workgroup, spread over counters that a caller with room for them keeps in different 128-byte lines: atomics on
@@ -49,21 +76,22 @@ __device__ inline uint32_t ray_key(const float *r, const float lo_x, const float
 // incoherent rays on 64 neighbouring words, took 5 ms).
 __global__ __launch_bounds__(kBlock) void k_ray_keys(const float *rays, const uint32_t n, const float lo_x, const float lo_y,
                                                     const float lo_z, const float sx, const float sy, const float sz,
-                                                    uint32_t *keys, uint32_t *index, uint32_t *descents, const uint32_t stride)
+                                                    uint32_t *keys, uint32_t *index, uint32_t *descents, const uint32_t stride,
+                                                    uint32_t *direction_keys)
 {
-	__shared__ uint32_t block_descents, block_spread;
+	__shared__ uint32_t block_descents, block_spread, block_elsewhere;
 	if (threadIdx.x == 0)
-		block_descents = block_spread = 0;
+		block_descents = block_spread = block_elsewhere = 0;
 	__syncthreads();
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-	bool descent = false, apart = false;
+	bool descent = false, apart = false, elsewhere = false;
 	if (i < n) {
 		const float *r = rays + (size_t)i * 6;
 		const uint32_t key = ray_key(r, lo_x, lo_y, lo_z, sx, sy, sz);
 		keys[i] = key;
 		index[i] = i;
 		descent = i > 0 && key < ray_key(rays + (size_t)(i - 1) * 6, lo_x, lo_y, lo_z, sx, sy, sz);
-		if (stride >= 2) {
+		if (stride >= 3) {
 			// does this ray travel with the first ray of its wave?  Directions within 2 degrees (cos^2 = 0.99878), origins
 			// within 2 of the 128 cells per axis that the keys are made of; NaNs count as apart
 			const float *f = rays + (size_t)(i & ~63u) * 6;
@@ -71,9 +99,16 @@ __global__ __launch_bounds__(kBlock) void k_ray_keys(const float *rays, const ui
 			const float d2 = r[3] * r[3] + r[4] * r[4] + r[5] * r[5], f2 = f[3] * f[3] + f[4] * f[4] + f[5] * f[5];
 			const float ox = (r[0] - f[0]) * sx, oy = (r[1] - f[1]) * sy, oz = (r[2] - f[2]) * sz;
 			apart = !(dd > 0.f && dd * dd >= 0.99878f * d2 * f2 && ox * ox + oy * oy + oz * oz <= 4.f);
+			// does it start where the batch's first ray starts (a pinhole camera's rays do)?
+			const float px = (r[0] - rays[0]) * sx, py = (r[1] - rays[1]) * sy, pz = (r[2] - rays[2]) * sz;
+			elsewhere = !(px * px + py * py + pz * pz <= 1e-8f);
 		}
+		if (direction_keys)
+			direction_keys[i] = direction_key(r);
 	}
-	const unsigned long long votes = __ballot(descent), spread = __ballot(apart);
+	const unsigned long long votes = __ballot(descent), spread = __ballot(apart), others = __ballot(elsewhere);
+	if ((threadIdx.x & 63) == 0 && others)
+		atomicAdd(&block_elsewhere, 1u);
 	if ((threadIdx.x & 63) == 0 && votes)
 		atomicAdd(&block_descents, (uint32_t)__popcll(votes));
 	if ((threadIdx.x & 63) == 0 && spread)
@@ -83,6 +118,8 @@ __global__ __launch_bounds__(kBlock) void k_ray_keys(const float *rays, const ui
 		atomicAdd(descents + (size_t)(blockIdx.x % kDescentCounters) * stride, block_descents);
 	if (threadIdx.x == 0 && block_spread)
 		atomicAdd(descents + (size_t)(blockIdx.x % kDescentCounters) * stride + 1, block_spread);
+	if (threadIdx.x == 0 && block_elsewhere)
+		atomicAdd(descents + (size_t)(blockIdx.x % kDescentCounters) * stride + 2, block_elsewhere);
 }
 
 }  // namespace
@@ -91,27 +128,27 @@ size_t ray_order_temp_bytes(uint32_t n)
 {
 	size_t bytes = 0;
 	uint32_t *none = nullptr;
-	(void)rocprim::radix_sort_pairs(nullptr, bytes, none, none, none, none, n, 0, kKeyBits, hipStream_t(nullptr));
+	(void)rocprim::radix_sort_pairs(nullptr, bytes, none, none, none, none, n, 0, 32u, hipStream_t(nullptr));
 	return bytes;
 }
 
 void launch_ray_keys(hipStream_t s, const float *rays, uint32_t n, const float box_lo[3], const float box_hi[3], uint32_t *keys,
-                     uint32_t *index, uint32_t *descents, uint32_t stride)
+                     uint32_t *index, uint32_t *descents, uint32_t stride, uint32_t *direction_keys)
 {
 	float scale[3];
 	for (int k = 0; k < 3; k++) {
 		const float extent = box_hi[k] - box_lo[k];
 		scale[k] = extent > 0.f ? 128.f / extent : 0.f;
 	}
-	(void)hipMemsetAsync(descents, 0, ((size_t)(kDescentCounters - 1) * stride + (stride >= 2 ? 2 : 1)) * sizeof(uint32_t), s);
+	(void)hipMemsetAsync(descents, 0, ((size_t)(kDescentCounters - 1) * stride + (stride >= 3 ? 3 : 1)) * sizeof(uint32_t), s);
 	hipLaunchKernelGGL(k_ray_keys, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, rays, n, box_lo[0], box_lo[1], box_lo[2],
-	                   scale[0], scale[1], scale[2], keys, index, descents, stride);
+	                   scale[0], scale[1], scale[2], keys, index, descents, stride, direction_keys);
 }
 
 hipError_t launch_ray_sort(hipStream_t s, uint32_t n, uint32_t *keys, uint32_t *keys_sorted, uint32_t *index, uint32_t *order,
-                           void *temp, size_t temp_bytes)
+                           void *temp, size_t temp_bytes, bool all_bits)
 {
-	return rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_sorted, index, order, n, 0, kKeyBits, s);
+	return rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_sorted, index, order, n, 0, all_bits ? 32u : kKeyBits, s);
 }
 
 }  // namespace rta

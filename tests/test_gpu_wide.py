@@ -312,16 +312,20 @@ def test_rays_that_travel_together_walk_the_tree_together(gpu, monkeypatch):
     for origin in ((-3.0, 0.0, 0.0), (0.1, 0.2, -0.3)):
         rr = np.concatenate([np.broadcast_to(np.float32(origin), d.shape), d], axis=1).astype(np.float32)
         got, st = traced(rr)
-        assert st["walked"] == 1 and st["packets"] == 1 and st["sorted"] == 0, st
+        assert st["walked"] == 1 and st["packets"] == 1 and st["sorted"] == 1, st
         idx = checked(rr, got)
         assert (idx >= 0).mean() > 0.2
-    # rays in order that do not travel together keep the walk of their own
+    # rays in order that do not travel together, or that start in different places, keep the walk of their own
     rng = np.random.default_rng(5)
     spread = rr.copy()
     spread[:, 3:6] = rng.standard_normal((len(rr), 3)).astype(np.float32)
-    got, st = traced(spread)
-    assert st["packets"] == 0, st
-    checked(spread, got)
+    parallel = rr.copy()
+    parallel[:, 0:3] = np.stack([np.full(len(rr), -3.0), y.reshape(-1) * 10, z.reshape(-1) * 10], axis=1)
+    parallel[:, 3:6] = np.float32([1, 0, 0])
+    for other in (spread, parallel):
+        got, st = traced(other)
+        assert st["packets"] == 0, st
+        checked(other, got)
     # forced: random rays in packets
     monkeypatch.setenv("RTA_BATCH_PACKETS", "2")
     lo, hi = np.full(3, -1.1), np.full(3, 1.1)

@@ -12,7 +12,7 @@ OUT := raytracer_amd
 CXXFLAGS := -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Iinclude -I$(SRC) -Wall -Wno-unused-result
 HIPFLAGS := --offload-arch=$(ARCH) $(CXXFLAGS)
 
-OBJS := build/kernels.o build/bvh_build.o build/sort_rays.o build/static_trace.o build/upload_device.o build/context.o build/api.o build/host_scene.o build/wide_tree.o
+OBJS := build/kernels.o build/cells.o build/bvh_build.o build/sort_rays.o build/static_trace.o build/upload_device.o build/context.o build/api.o build/host_scene.o build/wide_tree.o
 PROBE_OBJS := build/variants.o build/probe_api.o
 HDRS := $(wildcard $(SRC)/*.hpp) include/raytracer_amd.h include/raytracer_amd_probe.h include/rt_pmath.h
 

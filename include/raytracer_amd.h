@@ -280,6 +280,8 @@ typedef struct {
 	                                         * answer (an exact tie, a hit on the rim of its leaf's box, ...) and that the
 	                                         * order-replaying traversal answered instead */
 	uint64_t walked_rays;                   /* of `rays`: handed to the walk over the wide tree (0 for scenes without one) */
+	uint64_t listed_rays;                   /* of `rays`: a pinhole camera's rays answered from the triangle list of their cell
+	                                         * on the image plane, without a tree (retraced ones included) */
 } rta_stats;
 
 /* The render loop.  Replaces src/main.cpp:657-714 (row loop, per-sample ray

@@ -1017,6 +1017,15 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		                       : 0u;
 		base.hint = base.camera_walk && (hints ? atoi(hints) != 0 : true) ? ctx->hint.as<int32_t>() : nullptr;
 	}
+	// ... or are answered without any tree, from the triangle lists of their cells on the image plane (cells.hip),
+	// where samples can be placed on the image plane at all (the conditions of the sky map)
+	const int map_w = p->width + 2 * kSkyBorder, map_h = p->height + 2 * kSkyBorder;
+	const size_t n_cells = (size_t)map_w * (size_t)map_h;
+	bool want_cells = false;
+	{
+		static const char *cells = getenv("RTA_CAMERA_CELLS");      // measurement
+		want_cells = base.camera_walk && with_sky_map && n_cells < ((size_t)1 << 30) && (cells ? atoi(cells) != 0 : true);
+	}
 	// the walk's thresholds: idle lanes that make a wave draw new rays, lanes with a listed triangle (lanes with
 	// nothing else to do) that make it run the triangle test.  Measured on dragon.txt, camera and bounce rays:
 	// refill at 8 / 16 / 32 loses 4 / 1 / 0 %, quorum 16 or 32 loses 1 %, waiting 8 or 32 within 0.5 %.
@@ -1063,7 +1072,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	rta_context::Prepared &pre = ctx->prepared;
 	const bool reuse = pre.valid && memcmp(&pre.cam, camera, sizeof(rta_camera)) == 0 && pre.width == p->width &&
 	                   pre.height == p->height && pre.shard_index == p->shard_index && pre.shard_count == n_shards &&
-	                   pre.lane_blocks == lane_blocks && pre.with_sky_map == with_sky_map;
+	                   pre.lane_blocks == lane_blocks && pre.with_sky_map == with_sky_map && pre.want_cells == want_cells;
 	pre.valid = false;
 	if (n_pad && !reuse)
 		HIP_TRY_R(hipMemcpyAsync(ctx->pixels.ptr, px.data(), (size_t)n_pad * 4, hipMemcpyHostToDevice, s));
@@ -1071,6 +1080,34 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	if (with_sky_map && !reuse)
 		launch_sky_map(s, base.tree, ctx->n_pairs, projection, (uint32_t)p->width, (uint32_t)p->height,
 		               ctx->cover.as<uint8_t>(), ctx->sky_map.as<float>());
+	bool with_cells = reuse ? pre.with_cells : false;
+	if (want_cells && !reuse) {
+		const size_t temp_bytes = cell_scan_temp_bytes(n_cells + 1);
+		HIP_TRY_R(ctx->cell_counts.reserve((n_cells + 1) * 4));
+		HIP_TRY_R(ctx->cell_starts.reserve((n_cells + 1) * 4));
+		HIP_TRY_R(ctx->cell_temp.reserve(std::max<size_t>(temp_bytes, 16)));
+		HIP_TRY_R(launch_cell_count(s, base.tree, ctx->wide_n_nodes, projection, (double)ctx->wide_span, map_w, map_h,
+		                            ctx->cell_counts.as<uint32_t>(), ctx->cell_starts.as<uint32_t>(), ctx->cell_temp.ptr, temp_bytes));
+		uint32_t entries = 0;
+		HIP_TRY_R(hipMemcpyAsync(&entries, ctx->cell_starts.as<uint32_t>() + n_cells, 4, hipMemcpyDeviceToHost, s));
+		HIP_TRY_R(hipStreamSynchronize(s));
+		// (lists of a scene whose triangles all cover the frame would be of no use)
+		if (entries <= (1u << 28)) {
+			HIP_TRY_R(ctx->cell_list.reserve(std::max<size_t>(entries, 1) * 4));
+			HIP_TRY_R(launch_cell_fill(s, base.tree, ctx->wide_n_nodes, projection, (double)ctx->wide_span, map_w, map_h,
+			                           ctx->cell_counts.as<uint32_t>(), ctx->cell_starts.as<uint32_t>(), ctx->cell_list.as<uint32_t>()));
+			with_cells = true;
+		}
+		pre.cell_entries = entries;
+	}
+	if (with_cells) {
+		base.camera_cells = 1;
+		base.hint = ctx->hint.as<int32_t>();
+		base.cell_start = ctx->cell_starts.as<const uint32_t>();
+		base.cell_list = ctx->cell_list.as<const uint32_t>();
+		base.cell_w = map_w;
+		base.cell_h = map_h;
+	}
 	// Heaviest parts of the image first: one ray per pixel tells which parts see
 	// geometry, a counting sort (stable, so equal parts keep their order) makes the
 	// list the waves draw their items from.
@@ -1117,6 +1154,8 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	pre.shard_count = n_shards;
 	pre.lane_blocks = lane_blocks;
 	pre.with_sky_map = with_sky_map;
+	pre.want_cells = want_cells;
+	pre.with_cells = with_cells;
 	pre.n_listed = n_listed;
 	pre.n_far = n_far;
 	pre.far_pixels = far_pixels;
@@ -1288,6 +1327,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 			st.sph_tests += c.sph;
 			st.retraced_rays += c.retraced;
 			st.walked_rays += c.walked;
+			st.listed_rays += c.listed;
 		}
 		// all groups are idle here (synchronised above)
 		if (d_frame && n_owned)

@@ -77,6 +77,7 @@ struct rta_context {
 	rta::DeviceBuffer ray0, ray1, hit, thr, col, rng, acc, meta, hint, q_ray, q_bounce, shadow, partial, pixels, frame, bgr, counters;
 	rta::DeviceBuffer part_weights, part_order;
 	rta::DeviceBuffer cover, sky_map;         // see k_sky_map
+	rta::DeviceBuffer cell_counts, cell_starts, cell_list, cell_temp;     // per-cell triangle lists of the prepared view (cells.hip)
 	rta::DeviceBuffer ray_order;              // see tracing_order
 	rta::DeviceBuffer doubts;                 // rays a batch's certified walk hands on to the exact traversal
 	rta::DeviceBuffer io_a, io_b, io_c;       // staging for host-pointer calls
@@ -96,6 +97,8 @@ struct rta_context {
 		int32_t width = 0, height = 0, shard_index = 0, shard_count = 0;
 		uint32_t lane_blocks = 0;
 		bool with_sky_map = false;
+		bool want_cells = false, with_cells = false;      // camera rays from per-cell triangle lists: asked for, built
+		uint32_t cell_entries = 0;
 		uint32_t n_listed = 0, n_far = 0;
 		uint64_t far_pixels = 0;
 	} prepared;

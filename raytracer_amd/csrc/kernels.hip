@@ -44,6 +44,7 @@
 #include "shading.hpp"
 #include "traverse.hpp"
 #include "traverse_wide.hpp"
+#include "traverse_cells.hpp"
 #include "traverse_packet.hpp"
 
 namespace rta {
@@ -177,8 +178,9 @@ RTA_DEV CameraDraws camera_draws(const RenderArgs &a, uint32_t &rng)
 	return d;
 }
 
-// One camera sample of pixel (pu, pv) from its random numbers (src/main.cpp:663-687).
-RTA_DEV Ray camera_ray(const RenderArgs &a, uint32_t pu, uint32_t pv, const CameraDraws &d)
+// One camera sample of pixel (pu, pv) from its random numbers (src/main.cpp:663-687).  `cell`: the cell of
+// the image-plane map (RenderArgs::cell_w x cell_h) that the sample is aimed at, -1 beyond the map.
+RTA_DEV Ray camera_ray(const RenderArgs &a, uint32_t pu, uint32_t pv, const CameraDraws &d, int32_t &cell)
 {
 	const V3 cam_o = mk(a.cam.origin[0], a.cam.origin[1], a.cam.origin[2]);
 	V3 origin = cam_o;
@@ -196,8 +198,11 @@ RTA_DEV Ray camera_ray(const RenderArgs &a, uint32_t pu, uint32_t pv, const Came
 	const V3 ul = mk(a.cam.upper_left[0], a.cam.upper_left[1], a.cam.upper_left[2]);
 	const V3 du = mk(a.cam.du[0], a.cam.du[1], a.cam.du[2]);
 	const V3 dv = mk(a.cam.dv[0], a.cam.dv[1], a.cam.dv[2]);
-	const V3 target = (ul + du * ((float)pu + .5f + ju)) + dv * ((float)pv + .5f + jv);
+	const float fx = (float)pu + .5f + ju, fy = (float)pv + .5f + jv;
+	const V3 target = (ul + du * fx) + dv * fy;
 	const V3 dir = unit(target - origin);
+	const int ix = (int)__builtin_floorf(fx) + kSkyBorder, iy = (int)__builtin_floorf(fy) + kSkyBorder;
+	cell = ix >= 0 && ix < a.cell_w && iy >= 0 && iy < a.cell_h ? iy * a.cell_w + ix : -1;
 	return Ray{origin, dir};
 }
 
@@ -332,7 +337,7 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 			const bool is_sphere = __float_as_int(s2.w) == RTA_PRIM_SPHERE;
 			// the slot's next camera ray goes through the same pixel (hints are triangles: the walk
 			// tests every sphere anyway)
-			if (a.hint && bounce == 0)
+			if (a.hint && bounce == 0 && !a.camera_cells)
 				a.hint[slot] = is_sphere ? -1 : prim;
 
 			// src/main.cpp:353-354,365-368
@@ -464,6 +469,7 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 	// sine and cosine (binary64 polynomials) would run for them alone trip after trip.
 	CameraDraws held = {0.f, 0.f, 0.f, 0.f};
 	const bool ray_later = a.sky_map != nullptr;
+	int32_t cell = -1;
 	for (uint32_t trip = 0;; trip++) {
 		if (ended) {
 			// the finished sample joins its block sum (src/main.cpp:689)
@@ -572,7 +578,7 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 				held = draws;
 				have_ray = true;
 			} else {
-				next_ray = camera_ray(a, sky_pu, sky_pv, draws);
+				next_ray = camera_ray(a, sky_pu, sky_pv, draws, cell);
 				have_ray = true;
 				answered = trip < a.fast_trips && misses_the_scene(a.tree, next_ray);
 			}
@@ -589,8 +595,10 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 	}
 
 	if (ray_later && need_ray)
-		next_ray = camera_ray(a, sky_pu, sky_pv, held);
+		next_ray = camera_ray(a, sky_pu, sky_pv, held, cell);
 	if (need_ray) {
+		if (a.camera_cells)
+			a.hint[slot] = cell;
 		a.acc[slot] = A;
 		a.rng[slot] = rng;
 		if (meta_changed)
@@ -634,8 +642,10 @@ RTA_DEV void step_housekeeping(const RenderArgs &a, int par)
 		const uint32_t n = threadIdx.x % kRayKinds != (uint32_t)kDoubtRays ? a.cnt->n_ray[ray_queue_index(par, 0, 0) + threadIdx.x] : 0;
 		if (n)
 			atomicAdd(&a.cnt->rays, (unsigned long long)n);
-		if (n && a.wide_cap && (threadIdx.x % kRayKinds == (uint32_t)kBounceRays || (a.camera_walk && threadIdx.x % kRayKinds == (uint32_t)kCameraRays)))
+		if (n && a.wide_cap && (threadIdx.x % kRayKinds == (uint32_t)kBounceRays || (a.camera_walk && !a.camera_cells && threadIdx.x % kRayKinds == (uint32_t)kCameraRays)))
 			atomicAdd(&a.cnt->walked, (unsigned long long)n);
+		if (n && a.camera_cells && threadIdx.x % kRayKinds == (uint32_t)kCameraRays)
+			atomicAdd(&a.cnt->listed, (unsigned long long)n);
 		a.cnt->n_ray[ray_queue_index(par ^ 1, 0, 0) + threadIdx.x] = 0;
 	}
 	if (threadIdx.x < 2 * kShards)
@@ -673,7 +683,36 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 		return;
 	// with camera_walk the camera rays' workgroups pull them through the walk as the bounce rays' do
 	const bool camera_pulls = WIDE && a.camera_walk && blockIdx.x >= n_pulling;
-	if (blockIdx.x < n_pulling || camera_pulls) {
+	if (WIDE && a.camera_cells && blockIdx.x >= n_pulling) {
+		// camera rays answered from the triangle lists of their cells on the image plane, one ray per lane
+		const uint32_t rem = blockIdx.x - n_pulling;
+		const uint32_t shard = rem % kShards, part = rem / kShards;
+		const uint32_t q = ray_queue_index(par, kCameraRays, shard);
+		const uint32_t total = a.cnt->n_ray[q];
+		const uint32_t i = part * kBlock + threadIdx.x;
+		const bool active = i < total;
+		uint32_t slot = 0;
+		int32_t cell = -1;
+		Ray ray = {mk(0, 0, 0), mk(1, 1, 1)};
+		if (active) {
+			slot = a.q_ray[(size_t)q * a.shard_cap + i];
+			ray = slot_ray(a, slot);
+			cell = a.hint[slot];
+		}
+		HitRec h;
+		bool doubt;
+		closest_from_cell<COUNT>(a.tree, active, ray, cell, a.cell_start, a.cell_list, h, doubt, wc);
+		if (active && !doubt)
+			a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
+		// a ray whose answer is not proven goes to the exact traversal (k_intersect_odd)
+		const bool again = active && doubt;
+		if (__ballot(again)) {
+			const uint32_t qd = ray_queue_index(par, kDoubtRays, shard);
+			const uint32_t at = queue_push(again, &a.cnt->n_ray[qd]);
+			if (again)
+				a.q_ray[(size_t)qd * a.shard_cap + at] = slot;
+		}
+	} else if (blockIdx.x < n_pulling || camera_pulls) {
 		const uint32_t block = camera_pulls ? blockIdx.x - n_pulling : blockIdx.x;
 		const int kind = camera_pulls ? kCameraRays : kBounceRays;
 		const uint32_t shard = block % kShards, part = block / kShards;

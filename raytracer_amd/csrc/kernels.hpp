@@ -33,6 +33,7 @@ struct Counters {
 	unsigned long long early[kShards];
 	unsigned long long retraced;            // closest-hit queries that the certified walk left to the exact traversal
 	unsigned long long walked;              // closest-hit queries handed to the certified walk (retraced ones included)
+	unsigned long long listed;              // camera rays answered from their cell's triangle list (retraced ones included)
 };
 
 struct TreeRef {
@@ -97,6 +98,12 @@ struct RenderArgs {
 	uint32_t camera_walk;          // camera rays take the certified walk too (the camera lies within the wide tree's reach)
 	int32_t *hint;                 //   and start with the triangle the slot's last camera ray hit, [slot]; -1: none
 	uint32_t wide_cap;             // > 0: bounce rays take the certified walk over the wide tree, with this many LDS entries per lane
+	// Camera rays answered from per-cell triangle lists (cells.hip) instead: `hint` then holds the cell of the
+	// slot's camera ray (its place on the image plane, -1: none), cell_start[cell] .. cell_start[cell + 1] are
+	// the cell's entries of cell_list (triangle numbers)
+	uint32_t camera_cells;
+	const uint32_t *cell_start, *cell_list;
+	int32_t cell_w, cell_h;        // the map: the frame and kSkyBorder cells around it
 	// occlusion queue, 3 per entry: (origin, limit) (direction, slot) (radiance, -)
 	float4 *shadow;
 	Counters *cnt;                 // this group's
@@ -151,6 +158,14 @@ constexpr int kSkyBorder = 3;     // cells around the frame that the cover map i
 // cover: (width + 2 kSkyBorder) x (height + 2 kSkyBorder) bytes; sky_map: width x height floats
 void launch_sky_map(hipStream_t s, const TreeRef &tree, uint32_t n_pairs, const Projection &pr, uint32_t width,
                     uint32_t height, uint8_t *cover, float *sky_map);
+// cells.hip: per-cell triangle lists of a pinhole camera.  counts, starts: map_w x map_h + 1 words each; `span`: no admitted
+// origin is further from a vertex (WideTree::span).  The count pass leaves the number of entries in starts[map_w x map_h];
+// the fill pass writes them into `list`.
+size_t cell_scan_temp_bytes(size_t n);
+hipError_t launch_cell_count(hipStream_t s, const TreeRef &tree, uint32_t n_wide, const Projection &pr, double span, int map_w,
+                             int map_h, uint32_t *counts, uint32_t *starts, void *temp, size_t temp_bytes);
+hipError_t launch_cell_fill(hipStream_t s, const TreeRef &tree, uint32_t n_wide, const Projection &pr, double span, int map_w,
+                            int map_h, uint32_t *counts, const uint32_t *starts, uint32_t *list);
 void launch_intersect(hipStream_t s, const RenderArgs &a, int par, int depth, bool count);
 void launch_shadow(hipStream_t s, const RenderArgs &a, int depth, bool count);
 void launch_sum_blocks(hipStream_t s, const float4 *partial, const int32_t *pixels, uint32_t n_pad, uint32_t n_blocks,

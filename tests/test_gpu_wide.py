@@ -186,7 +186,11 @@ def test_render_with_and_without_the_wide_tree(gpu):
     assert bounce > 100000 and st_a["retraced_rays"] < bounce // 1000
     # all bounce rays but those that need the division-based box test, and the camera rays where the camera is in reach
     assert bounce * 0.99 <= st_a["walked_rays"] <= st_a["rays"] - st_a["early_rays"]
-    assert st_a["walked_rays"] > bounce      # dragon.txt's camera is: its rays walk too, each hinted at the slot's last hit
+    # dragon.txt's camera is a pinhole in reach: its rays are answered from the triangle lists of their cells
+    # on the image plane, every one that is traced at all
+    traced_camera = st_a["samples"] - st_a["early_rays"]
+    assert 0.999 * traced_camera <= st_a["listed_rays"] <= traced_camera and st_b["listed_rays"] == 0
+    assert st_a["walked_rays"] + st_a["listed_rays"] <= st_a["rays"] - st_a["early_rays"]
 
 
 def test_a_few_spheres_beside_the_mesh(gpu):

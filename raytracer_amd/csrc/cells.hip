@@ -23,8 +23,17 @@
 // orders of magnitude below Projection::margin (see projection_of in context.cpp).  A cell gets the
 // triangle unless some edge of the projected triangle, moved outwards by sqrt(rx^2 + ry^2) + margin,
 // has the whole cell on its far side (or the cell lies outside the bounding rectangle moved likewise).
+//
+// Nearest first.  Every entry carries a lower bound of the distance at which the test can accept its
+// triangle for a ray through the cell, and a cell's entries are sorted by it, so that the tests can stop at
+// the first entry whose bound lies beyond the nearest hit so far.  A camera ray's direction is normalised
+// (|d| within 1 +- 1e-6), so its parameter at X is |X - o| up to that factor, and X lies at least
+// (depth - rho) sec(theta) from the pinhole: depth = the least distance of the triangle's vertices from the
+// pinhole along the camera's axis, theta = the least angle to that axis of any ray through the cell; the
+// computed t lies within dt = 16.02e4 u E^2 (S + E) + u t of the parameter at X (wide_tree.cpp).
 #include "kernels.hpp"
 
+#include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
 namespace rta {
@@ -39,6 +48,10 @@ struct Outline {
 	bool everywhere;        // no statement about this triangle: it joins every cell
 	bool edges;             // the three edge tests apply (a proper triangle on the image plane)
 	double mx[3], my[3];    // outward unit normals of the edges k -> k + 1
+	double depth;           // least distance of a point within rho of the triangle from the pinhole, along the camera's axis
+	double dt;              // see above (without the u t part)
+	double ppx, ppy;        // where the camera's axis meets the image plane, pixel coordinates
+	double tan2_x, tan2_y;  // (a pixel's width, height / the image plane's distance)^2
 	int i0, i1, j0, j1;     // cells of the bounding rectangle, clipped to the map (empty when i1 < i0 or j1 < j0)
 };
 
@@ -107,6 +120,13 @@ __device__ Outline outline_of(const TreeRef &tree, const uint32_t prim, const Pr
 			t.everywhere = true;
 	}
 	t.widen = widen;
+	t.depth = t.everywhere ? 0 : (z_min / n_len - rho) * (1 - 1e-9);
+	t.dt = 16.02e4 * u * edge * edge * (span + edge) * (1 + 1e-9);
+	t.ppx = -cx;
+	t.ppy = -cy;
+	const double plane = h_abs / n_len;
+	t.tan2_x = pr.du2 / (plane * plane);
+	t.tan2_y = pr.dv2 / (plane * plane);
 	double x0 = -1e9, x1 = 1e9, y0 = -1e9, y1 = 1e9;
 	t.edges = false;
 	if (!t.everywhere) {
@@ -161,12 +181,32 @@ __device__ bool touches(const Outline &t, const int ci, const int cj)
 	return true;
 }
 
+// lower bound of the t that HitTriangle can return for the triangle and a camera ray through the cell
+__device__ float nearest_t(const Outline &t, const int ci, const int cj)
+{
+	if (t.everywhere || !(t.depth > 0))
+		return 0.f;
+	// the point of the cell (widened by a pixel: far more than the margin) nearest to the camera's axis
+	const double x0 = (double)(ci - kSkyBorder) - 1, x1 = x0 + 3, y0 = (double)(cj - kSkyBorder) - 1, y1 = y0 + 3;
+	const double dx = t.ppx < x0 ? x0 - t.ppx : (t.ppx > x1 ? t.ppx - x1 : 0), dy = t.ppy < y0 ? y0 - t.ppy : (t.ppy > y1 ? t.ppy - y1 : 0);
+	const double sec = sqrt(1 + dx * dx * t.tan2_x + dy * dy * t.tan2_y);
+	const double bound = (t.depth * sec * (1 - 2e-6) - t.dt) * (1 - 1e-6);
+	if (!(bound > 0))
+		return 0.f;
+	float f = (float)bound;
+	if ((double)f > bound)
+		f = __uint_as_float(__float_as_uint(f) - 1);      // (positive: the next float down)
+	return f;
+}
+
 // One wave per child reference of a wide node (gridDim.y waves for big outlines); FILL: the second pass,
-// which writes the triangle into the lists whose lengths the first pass counted.
+// which writes the triangle and its key - cell number, then the bits of nearest_t - into the lists whose
+// lengths the first pass counted.
 template <bool FILL>
 __global__ __launch_bounds__(kCellBlock) void k_cell_lists(const TreeRef tree, const uint32_t n_wide, const Projection pr,
                                                            const double span, const int map_w, const int map_h,
-                                                           uint32_t *counts, const uint32_t *starts, uint32_t *list)
+                                                           uint32_t *counts, const uint32_t *starts, uint32_t *list,
+                                                           unsigned long long *keys)
 {
 	const uint32_t item = blockIdx.x * (kCellBlock / 64) + threadIdx.x / 64, lane = threadIdx.x & 63;
 	if (item >= 4 * n_wide)
@@ -185,8 +225,10 @@ __global__ __launch_bounds__(kCellBlock) void k_cell_lists(const TreeRef tree, c
 			continue;
 		const size_t cell = (size_t)cj * map_w + ci;
 		const uint32_t at = atomicAdd(&counts[cell], 1u);
-		if (FILL)
+		if (FILL) {
 			list[starts[cell] + at] = prim;
+			keys[starts[cell] + at] = ((unsigned long long)cell << 32) | __float_as_uint(nearest_t(t, ci, cj));
+		}
 	}
 }
 
@@ -215,21 +257,37 @@ hipError_t launch_cell_count(hipStream_t s, const TreeRef &tree, uint32_t n_wide
 	if (e != hipSuccess)
 		return e;
 	hipLaunchKernelGGL(k_cell_lists<false>, cell_grid(n_wide), dim3(kCellBlock), 0, s, tree, n_wide, pr, span, map_w, map_h, counts,
-	                   (const uint32_t *)nullptr, (uint32_t *)nullptr);
+	                   (const uint32_t *)nullptr, (uint32_t *)nullptr, (unsigned long long *)nullptr);
 	// starts[cell] = entries before the cell's; starts[cells] = all entries
 	return rocprim::exclusive_scan(temp, temp_bytes, counts, starts, 0u, n, rocprim::plus<uint32_t>(), s);
 }
 
+size_t cell_sort_temp_bytes(size_t entries)
+{
+	size_t bytes = 0;
+	unsigned long long *no_keys = nullptr;
+	uint32_t *no_values = nullptr;
+	(void)rocprim::radix_sort_pairs(nullptr, bytes, no_keys, no_keys, no_values, no_values, entries, 0u, 64u, hipStream_t(nullptr));
+	return bytes;
+}
+
 hipError_t launch_cell_fill(hipStream_t s, const TreeRef &tree, uint32_t n_wide, const Projection &pr, double span, int map_w,
-                            int map_h, uint32_t *counts, const uint32_t *starts, uint32_t *list)
+                            int map_h, uint32_t *counts, const uint32_t *starts, size_t entries, uint32_t *list_unsorted,
+                            unsigned long long *keys_unsorted, uint32_t *list, unsigned long long *keys, void *temp, size_t temp_bytes)
 {
 	const size_t n = (size_t)map_w * map_h + 1;
 	hipError_t e = hipMemsetAsync(counts, 0, n * sizeof(uint32_t), s);
 	if (e != hipSuccess)
 		return e;
 	hipLaunchKernelGGL(k_cell_lists<true>, cell_grid(n_wide), dim3(kCellBlock), 0, s, tree, n_wide, pr, span, map_w, map_h, counts,
-	                   starts, list);
-	return hipGetLastError();
+	                   starts, list_unsorted, keys_unsorted);
+	if ((e = hipGetLastError()) != hipSuccess || entries == 0)
+		return e;
+	// by cell, then nearest first (the cells' entries are contiguous already: `starts` stays valid)
+	uint32_t cell_bits = 1;
+	while (cell_bits < 32 && (n >> cell_bits))
+		cell_bits++;
+	return rocprim::radix_sort_pairs(temp, temp_bytes, keys_unsorted, keys, list_unsorted, list, entries, 0u, 32u + cell_bits, s);
 }
 
 }  // namespace rta

@@ -903,7 +903,8 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	// (measured at 4..32 waiting lanes) fills idle lanes but loses more than it
 	// gains: the wave's camera rays stop coming from one part of the image at one
 	// sample index.
-	const uint32_t grab_at = 64;
+	static const char *grab_env = getenv("RTA_GRAB_AT");      // measurement
+	const uint32_t grab_at = grab_env ? (uint32_t)std::min(std::max(atoi(grab_env), 1), 64) : 64u;
 
 	// workspace (grow-only, reused across calls)
 	const size_t S = (size_t)max_group_blocks * 256 * groups;
@@ -1092,19 +1093,29 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		HIP_TRY_R(hipMemcpyAsync(&entries, ctx->cell_starts.as<uint32_t>() + n_cells, 4, hipMemcpyDeviceToHost, s));
 		HIP_TRY_R(hipStreamSynchronize(s));
 		// (lists of a scene whose triangles all cover the frame would be of no use)
-		if (entries <= (1u << 28)) {
-			HIP_TRY_R(ctx->cell_list.reserve(std::max<size_t>(entries, 1) * 4));
+		if (entries <= (1u << 26)) {
+			const size_t room = std::max<size_t>(entries, 1), sort_bytes = cell_sort_temp_bytes(room);
+			HIP_TRY_R(ctx->cell_list.reserve(room * 4));
+			HIP_TRY_R(ctx->cell_keys.reserve(room * 8));
+			HIP_TRY_R(ctx->cell_unsorted.reserve(room * 12));      // keys, then triangle numbers
+			HIP_TRY_R(ctx->cell_temp.reserve(std::max<size_t>(sort_bytes, 16)));
 			HIP_TRY_R(launch_cell_fill(s, base.tree, ctx->wide_n_nodes, projection, (double)ctx->wide_span, map_w, map_h,
-			                           ctx->cell_counts.as<uint32_t>(), ctx->cell_starts.as<uint32_t>(), ctx->cell_list.as<uint32_t>()));
+			                           ctx->cell_counts.as<uint32_t>(), ctx->cell_starts.as<uint32_t>(), entries,
+			                           reinterpret_cast<uint32_t *>(ctx->cell_unsorted.as<unsigned long long>() + room),
+			                           ctx->cell_unsorted.as<unsigned long long>(), ctx->cell_list.as<uint32_t>(),
+			                           ctx->cell_keys.as<unsigned long long>(), ctx->cell_temp.ptr, sort_bytes));
 			with_cells = true;
 		}
 		pre.cell_entries = entries;
 	}
 	if (with_cells) {
 		base.camera_cells = 1;
+		static const char *first_hit = getenv("RTA_SHADE_FIRST_HIT");      // measurement
+		base.shade_first_hit = ctx->n_lights == 0 && (first_hit ? atoi(first_hit) != 0 : true) ? 1u : 0u;
 		base.hint = ctx->hint.as<int32_t>();
 		base.cell_start = ctx->cell_starts.as<const uint32_t>();
 		base.cell_list = ctx->cell_list.as<const uint32_t>();
+		base.cell_keys = ctx->cell_keys.as<const unsigned long long>();
 		base.cell_w = map_w;
 		base.cell_h = map_h;
 	}

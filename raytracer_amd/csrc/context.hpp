@@ -77,7 +77,7 @@ struct rta_context {
 	rta::DeviceBuffer ray0, ray1, hit, thr, col, rng, acc, meta, hint, q_ray, q_bounce, shadow, partial, pixels, frame, bgr, counters;
 	rta::DeviceBuffer part_weights, part_order;
 	rta::DeviceBuffer cover, sky_map;         // see k_sky_map
-	rta::DeviceBuffer cell_counts, cell_starts, cell_list, cell_temp;     // per-cell triangle lists of the prepared view (cells.hip)
+	rta::DeviceBuffer cell_counts, cell_starts, cell_list, cell_keys, cell_unsorted, cell_temp;     // per-cell triangle lists of the prepared view (cells.hip)
 	rta::DeviceBuffer ray_order;              // see tracing_order
 	rta::DeviceBuffer doubts;                 // rays a batch's certified walk hands on to the exact traversal
 	rta::DeviceBuffer io_a, io_b, io_c;       // staging for host-pointer calls

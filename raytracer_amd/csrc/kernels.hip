@@ -224,6 +224,122 @@ RTA_DEV bool misses_the_scene(const TreeRef &tree, const Ray &r)
 	return t_out < 0.f || t_out * (1.f + 0x1p-18f) < t_in;
 }
 
+// One bounce of RayTrace on a hit (src/main.cpp:516-588): emission, the light sample whose visibility an
+// occlusion query decides later, the BSDF sample, Russian roulette.  `bounce`: segments of the path before
+// this one; prev_pdf: pdf of the direction that led here; thr, color, rng: the path's, updated.
+// Returns whether the path goes on: along next_ray, whose direction was sampled with pdf next_pdf.
+struct ShadowQuery {
+	bool wanted;         // an occlusion query (o, d, limit dist) decides whether c joins the path's radiance
+	V3 o, d, c;
+	float dist;
+};
+
+RTA_DEV bool shade_hit(const RenderArgs &a, const uint32_t slot, const uint32_t bounce, const Ray &ray, const float prev_pdf,
+                       const float4 H, uint32_t &rng, V3 &thr, V3 &color, Ray &next_ray, float &next_pdf, ShadowQuery &shadow)
+{
+	const int32_t prim = __float_as_int(H.x);
+	const float t = H.y, bu = H.z, bv = H.w;
+	const float4 s0 = a.shade_prims[3 * (size_t)prim];
+	const float4 s1 = a.shade_prims[3 * (size_t)prim + 1];
+	const float4 s2 = a.shade_prims[3 * (size_t)prim + 2];
+	const int32_t mat_id = __float_as_int(s0.w), light_id = __float_as_int(s1.w);
+	const bool is_sphere = __float_as_int(s2.w) == RTA_PRIM_SPHERE;
+	// the slot's next camera ray goes through the same pixel (hints are triangles: the walk
+	// tests every sphere anyway)
+	if (a.hint && bounce == 0 && !a.camera_cells)
+		a.hint[slot] = is_sphere ? -1 : prim;
+
+	// src/main.cpp:353-354,365-368
+	const V3 point = ray.o + ray.d * t;
+	V3 normal;
+	if (is_sphere) {
+		const float4 g0 = a.tree.prims[kPrimQuads * (size_t)prim], g1 = a.tree.prims[kPrimQuads * (size_t)prim + 1];
+		normal = (point - xyz(g0)) / g1.x;
+	} else {
+		const float bw = 1 - bu - bv;
+		normal = unit((xyz(s0) * bu + xyz(s1) * bv) + xyz(s2) * bw);
+	}
+	bool front = true;
+	if (dot(ray.d, normal) > 0) {
+		normal = -normal;
+		front = false;
+	}
+	const float4 m0 = a.materials[2 * (size_t)mat_id], m1 = a.materials[2 * (size_t)mat_id + 1];
+	const Material mat = {xyz(m0), m0.w, m1.x, m1.y};
+
+	const Frame fr = frame_from_normal(normal);
+	const V3 v = to_local(fr, -ray.d);
+
+	// emitted light, MIS-weighted after the first bounce (src/main.cpp:531-543)
+	if (front && light_id >= 0) {
+		const float4 *L = a.lights + 7 * (size_t)light_id;
+		const V3 le = xyz(L[0]);
+		if (bounce == 0 || a.n_lights == 0) {
+			color = color + thr * le;
+		} else {
+			const float pmf = 1.f / (float)a.n_lights;
+			const float lpdf = pmf * triangle_pdf(xyz(L[1]), xyz(L[2]), xyz(L[3]), ray.o, point, normal);
+			const float w = power_heuristic(prev_pdf, lpdf);
+			color = color + (thr * le) * w;
+		}
+	}
+
+	// next-event estimation on one uniformly chosen triangle light
+	// (src/main.cpp:545-571); the visibility test is deferred to k_shadow
+	if (a.n_lights > 0) {
+		const uint32_t li = rng_next(rng) % (uint32_t)a.n_lights;
+		const float4 *L = a.lights + 7 * (size_t)li;
+		// src/main.cpp:115-131
+		const float r1u = rng_float(rng);
+		const float r2u = rng_float(rng);
+		float b0, b1;
+		if (r1u < r2u) {
+			b0 = r1u / 2;
+			b1 = r2u - b0;
+		} else {
+			b1 = r2u / 2;
+			b0 = r1u - b1;
+		}
+		const float b2 = 1 - b0 - b1;
+		const V3 lp = (xyz(L[1]) * b0 + xyz(L[2]) * b1) + xyz(L[3]) * b2;
+		const V3 ln = unit((xyz(L[4]) * b0 + xyz(L[5]) * b1) + xyz(L[6]) * b2);
+		V3 ld = lp - point;
+		const float dist = norm(ld);
+		ld = ld / dist;
+		const V3 l = to_local(fr, ld);
+		if (dot(ld, ln) < 0) {
+			const float pmf = 1.f / (float)a.n_lights;
+			const float lpdf = pmf * triangle_pdf(xyz(L[1]), xyz(L[2]), xyz(L[3]), point, lp, ln);
+			const float bpdf = bsdf_pdf(v, l, mat);
+			const float w = power_heuristic(lpdf, bpdf);
+			const V3 f = bsdf_eval(v, l, mat);
+			shadow.c = (((thr * xyz(L[0])) * f) * w) / lpdf;
+			shadow.o = point;
+			shadow.d = ld;
+			shadow.dist = dist - .0001f;
+			shadow.wanted = true;
+		}
+	}
+
+	// src/main.cpp:573-588
+	const BsdfSample bs = sample_bsdf(v, mat, rng);
+	thr = thr * (bs.f / bs.pdf);
+	bool stop = false;
+	if (bounce > 3) {
+		const float p = greater(thr.x, greater(thr.y, thr.z));
+		if (rng_float(rng) < (1 - p))
+			stop = true;
+		else
+			thr = thr / p;
+	}
+	if (!stop && bounce + 1 < (uint32_t)a.max_bounces) {
+		next_ray = Ray{point, to_world(fr, bs.l)};
+		next_pdf = bs.pdf;
+		return true;
+	}
+	return false;
+}
+
 // Everything between two traversals of a slot, in one pass over the slot state:
 //
 //   shade     one bounce of RayTrace on the hit the traversal left
@@ -300,10 +416,9 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 	if (__ballot(state != kRetired) == 0)
 		return;                   // whole waves leave together
 
-	bool want_shadow = false, alive = false, ended = false;
+	bool alive = false, ended = false;
 	Ray next_ray = {mk(0, 0, 0), mk(1, 1, 1)};
-	V3 sh_o = mk(0, 0, 0), sh_d = mk(0, 0, 0), sh_c = mk(0, 0, 0);
-	float sh_dist = 0;
+	ShadowQuery shadow = {false, mk(0, 0, 0), mk(0, 0, 0), mk(0, 0, 0), 0.f};
 	V3 color = mk(0, 0, 0);
 	uint32_t rng = 0;
 
@@ -327,114 +442,17 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 			float4 r0 = make_float4(a.cam.origin[0], a.cam.origin[1], a.cam.origin[2], 1.f);
 			if (bounce > 0 || !pinhole(a))
 				r0 = a.ray0[slot];
-			const Ray ray = {xyz(r0), xyz(r1)};
-			const float prev_pdf = r0.w;
-			const float t = H.y, bu = H.z, bv = H.w;
-			const float4 s0 = a.shade_prims[3 * (size_t)prim];
-			const float4 s1 = a.shade_prims[3 * (size_t)prim + 1];
-			const float4 s2 = a.shade_prims[3 * (size_t)prim + 2];
-			const int32_t mat_id = __float_as_int(s0.w), light_id = __float_as_int(s1.w);
-			const bool is_sphere = __float_as_int(s2.w) == RTA_PRIM_SPHERE;
-			// the slot's next camera ray goes through the same pixel (hints are triangles: the walk
-			// tests every sphere anyway)
-			if (a.hint && bounce == 0 && !a.camera_cells)
-				a.hint[slot] = is_sphere ? -1 : prim;
-
-			// src/main.cpp:353-354,365-368
-			const V3 point = ray.o + ray.d * t;
-			V3 normal;
-			if (is_sphere) {
-				const float4 g0 = a.tree.prims[kPrimQuads * (size_t)prim], g1 = a.tree.prims[kPrimQuads * (size_t)prim + 1];
-				normal = (point - xyz(g0)) / g1.x;
-			} else {
-				const float bw = 1 - bu - bv;
-				normal = unit((xyz(s0) * bu + xyz(s1) * bv) + xyz(s2) * bw);
-			}
-			bool front = true;
-			if (dot(ray.d, normal) > 0) {
-				normal = -normal;
-				front = false;
-			}
-			const float4 m0 = a.materials[2 * (size_t)mat_id], m1 = a.materials[2 * (size_t)mat_id + 1];
-			const Material mat = {xyz(m0), m0.w, m1.x, m1.y};
-
-			const Frame fr = frame_from_normal(normal);
-			const V3 v = to_local(fr, -ray.d);
-
-			// emitted light, MIS-weighted after the first bounce (src/main.cpp:531-543)
-			if (front && light_id >= 0) {
-				const float4 *L = a.lights + 7 * (size_t)light_id;
-				const V3 le = xyz(L[0]);
-				if (bounce == 0 || a.n_lights == 0) {
-					color = color + thr * le;
-				} else {
-					const float pmf = 1.f / (float)a.n_lights;
-					const float lpdf = pmf * triangle_pdf(xyz(L[1]), xyz(L[2]), xyz(L[3]), ray.o, point, normal);
-					const float w = power_heuristic(prev_pdf, lpdf);
-					color = color + (thr * le) * w;
-				}
-			}
-
-			// next-event estimation on one uniformly chosen triangle light
-			// (src/main.cpp:545-571); the visibility test is deferred to k_shadow
-			if (a.n_lights > 0) {
-				const uint32_t li = rng_next(rng) % (uint32_t)a.n_lights;
-				const float4 *L = a.lights + 7 * (size_t)li;
-				// src/main.cpp:115-131
-				const float r1u = rng_float(rng);
-				const float r2u = rng_float(rng);
-				float b0, b1;
-				if (r1u < r2u) {
-					b0 = r1u / 2;
-					b1 = r2u - b0;
-				} else {
-					b1 = r2u / 2;
-					b0 = r1u - b1;
-				}
-				const float b2 = 1 - b0 - b1;
-				const V3 lp = (xyz(L[1]) * b0 + xyz(L[2]) * b1) + xyz(L[3]) * b2;
-				const V3 ln = unit((xyz(L[4]) * b0 + xyz(L[5]) * b1) + xyz(L[6]) * b2);
-				V3 ld = lp - point;
-				const float dist = norm(ld);
-				ld = ld / dist;
-				const V3 l = to_local(fr, ld);
-				if (dot(ld, ln) < 0) {
-					const float pmf = 1.f / (float)a.n_lights;
-					const float lpdf = pmf * triangle_pdf(xyz(L[1]), xyz(L[2]), xyz(L[3]), point, lp, ln);
-					const float bpdf = bsdf_pdf(v, l, mat);
-					const float w = power_heuristic(lpdf, bpdf);
-					const V3 f = bsdf_eval(v, l, mat);
-					sh_c = (((thr * xyz(L[0])) * f) * w) / lpdf;
-					sh_o = point;
-					sh_d = ld;
-					sh_dist = dist - .0001f;
-					want_shadow = true;
-				}
-			}
-
-			// src/main.cpp:573-588
-			const BsdfSample bs = sample_bsdf(v, mat, rng);
-			thr = thr * (bs.f / bs.pdf);
-			bool stop = false;
-			if (bounce > 3) {
-				const float p = greater(thr.x, greater(thr.y, thr.z));
-				if (rng_float(rng) < (1 - p))
-					stop = true;
-				else
-					thr = thr / p;
-			}
-			if (!stop && bounce + 1 < (uint32_t)a.max_bounces) {
-				const V3 nd = to_world(fr, bs.l);
+			float next_pdf = 0.f;
+			alive = shade_hit(a, slot, bounce, Ray{xyz(r0), xyz(r1)}, r0.w, H, rng, thr, color, next_ray, next_pdf, shadow);
+			if (alive) {
 				// (with lights nearly every path gathers at once: not worth the test)
 				const bool gathered = a.n_lights > 0 || ((__float_as_uint(color.x) | __float_as_uint(color.y) | __float_as_uint(color.z)) != 0);
-				a.ray0[slot] = make_float4(point.x, point.y, point.z, bs.pdf);
-				a.ray1[slot] = make_float4(nd.x, nd.y, nd.z, __uint_as_float((bounce + 1) | (gathered ? kHasColour : 0u)));
+				a.ray0[slot] = make_float4(next_ray.o.x, next_ray.o.y, next_ray.o.z, next_pdf);
+				a.ray1[slot] = make_float4(next_ray.d.x, next_ray.d.y, next_ray.d.z, __uint_as_float((bounce + 1) | (gathered ? kHasColour : 0u)));
 				a.thr[slot] = f4(thr, 0.f);
-				next_ray = Ray{point, nd};
-				alive = true;
 			}
 		}
-		if (alive || want_shadow) {
+		if (alive || shadow.wanted) {
 			// the radiance so far is needed again: by the next bounce, or by the
 			// occlusion query that may add the light's share to it (nothing to keep while it is 0)
 			if (a.n_lights > 0 || ((__float_as_uint(color.x) | __float_as_uint(color.y) | __float_as_uint(color.z)) != 0))
@@ -620,12 +638,12 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 	ray_queues_push(a, par, need_ray, alive, slot, next_ray);
 	if (a.n_lights > 0) {
 		const uint32_t shard = blockIdx.x % kShards;
-		const uint32_t at_sh = queue_push(want_shadow, &a.cnt->n_shadow[shard]);
-		if (want_shadow) {
+		const uint32_t at_sh = queue_push(shadow.wanted, &a.cnt->n_shadow[shard]);
+		if (shadow.wanted) {
 			float4 *e = a.shadow + 3 * ((size_t)shard * a.shard_cap + at_sh);
-			e[0] = f4(sh_o, sh_dist);
-			e[1] = f4u(sh_d, slot);      // slot < n_slots here: want_shadow implies a live lane
-			e[2] = f4(sh_c, 0.f);
+			e[0] = f4(shadow.o, shadow.dist);
+			e[1] = f4u(shadow.d, slot);      // slot < n_slots here: a wanted query implies a live lane
+			e[2] = f4(shadow.c, 0.f);
 		}
 	}
 }
@@ -683,36 +701,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 		return;
 	// with camera_walk the camera rays' workgroups pull them through the walk as the bounce rays' do
 	const bool camera_pulls = WIDE && a.camera_walk && blockIdx.x >= n_pulling;
-	if (WIDE && a.camera_cells && blockIdx.x >= n_pulling) {
-		// camera rays answered from the triangle lists of their cells on the image plane, one ray per lane
-		const uint32_t rem = blockIdx.x - n_pulling;
-		const uint32_t shard = rem % kShards, part = rem / kShards;
-		const uint32_t q = ray_queue_index(par, kCameraRays, shard);
-		const uint32_t total = a.cnt->n_ray[q];
-		const uint32_t i = part * kBlock + threadIdx.x;
-		const bool active = i < total;
-		uint32_t slot = 0;
-		int32_t cell = -1;
-		Ray ray = {mk(0, 0, 0), mk(1, 1, 1)};
-		if (active) {
-			slot = a.q_ray[(size_t)q * a.shard_cap + i];
-			ray = slot_ray(a, slot);
-			cell = a.hint[slot];
-		}
-		HitRec h;
-		bool doubt;
-		closest_from_cell<COUNT>(a.tree, active, ray, cell, a.cell_start, a.cell_list, h, doubt, wc);
-		if (active && !doubt)
-			a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
-		// a ray whose answer is not proven goes to the exact traversal (k_intersect_odd)
-		const bool again = active && doubt;
-		if (__ballot(again)) {
-			const uint32_t qd = ray_queue_index(par, kDoubtRays, shard);
-			const uint32_t at = queue_push(again, &a.cnt->n_ray[qd]);
-			if (again)
-				a.q_ray[(size_t)qd * a.shard_cap + at] = slot;
-		}
-	} else if (blockIdx.x < n_pulling || camera_pulls) {
+	if (blockIdx.x < n_pulling || camera_pulls) {
 		const uint32_t block = camera_pulls ? blockIdx.x - n_pulling : blockIdx.x;
 		const int kind = camera_pulls ? kCameraRays : kBounceRays;
 		const uint32_t shard = block % kShards, part = block / kShards;
@@ -782,6 +771,90 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 			traverse_dyn<false, COUNT, true>(a.tree, ray, FLT_MAX, lds_stack + threadIdx.x, depth, h, wc);
 			a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
 		}
+	}
+	if (COUNT)
+		count_flush(a.cnt, wc);
+}
+
+// A pinhole camera's rays, answered from the triangle lists of their cells on the image plane
+// (traverse_cells.hpp, cells.hip), one ray per lane; runs before the step's k_intersect.  Grid: one workgroup
+// per kBlock entries of the camera sub-queues, shards innermost.
+//
+// With RenderArgs::shade_first_hit (scenes without lights) a ray that hits is shaded here as well - bounce 0
+// of RayTrace (src/main.cpp:507-589) with throughput 1 and radiance 0, from the slot's random stream where
+// k_advance left it - and its bounce ray joins the step's bounce queue, which k_intersect traces next: a
+// camera sample that hits takes one pass of k_advance less, and the lanes that shade are compact here.  A
+// slot's bounce ray goes to the sub-queue its camera ray came from (the slot's own, see ray_queues_push), so
+// no sub-queue receives more than its slots.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_camera_cells(const RenderArgs a, const int par)
+{
+	const uint32_t shard = blockIdx.x % kShards, part = blockIdx.x / kShards;
+	const uint32_t q = ray_queue_index(par, kCameraRays, shard);
+	const uint32_t total = a.cnt->n_ray[q];
+	if (part * kBlock >= total)
+		return;
+	const uint32_t i = part * kBlock + threadIdx.x;
+	const bool active = i < total;
+	uint32_t slot = 0;
+	int32_t cell = -1;
+	Ray ray = {mk(0, 0, 0), mk(1, 1, 1)};
+	if (active) {
+		slot = a.q_ray[(size_t)q * a.shard_cap + i];
+		ray = slot_ray(a, slot);
+		cell = a.hint[slot];
+	}
+	WorkCount wc = {0, 0, 0};
+	HitRec h;
+	bool doubt;
+	closest_from_cell<COUNT>(a.tree, active, ray, cell, a.cell_start, a.cell_list, a.cell_keys, h, doubt, wc);
+	bool onward = false;
+	Ray next_ray = {mk(0, 0, 0), mk(1, 1, 1)};
+	if (active && !doubt) {
+		const float4 H = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
+		if (a.shade_first_hit && h.prim >= 0) {
+			uint32_t rng = a.rng[slot];
+			V3 thr = mk(1, 1, 1), color = mk(0, 0, 0);
+			float next_pdf = 0.f;
+			ShadowQuery none = {false, mk(0, 0, 0), mk(0, 0, 0), mk(0, 0, 0), 0.f};      // (no lights: never wanted)
+			onward = shade_hit(a, slot, 0u, ray, 1.f, H, rng, thr, color, next_ray, next_pdf, none);      // (a pinhole's rays: pdf 1)
+			a.rng[slot] = rng;
+			const bool gathered = (__float_as_uint(color.x) | __float_as_uint(color.y) | __float_as_uint(color.z)) != 0;
+			if (onward) {
+				a.ray0[slot] = make_float4(next_ray.o.x, next_ray.o.y, next_ray.o.z, next_pdf);
+				a.ray1[slot] = make_float4(next_ray.d.x, next_ray.d.y, next_ray.d.z, __uint_as_float(1u | (gathered ? kHasColour : 0u)));
+				a.thr[slot] = f4(thr, 0.f);
+				if (gathered)
+					a.col[slot] = f4(color, 0.f);
+			} else {
+				// the sample is over: the next pass of k_advance retires it
+				a.col[slot] = f4(color, 0.f);
+				a.ray1[slot] = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(kEnded));
+			}
+		} else {
+			a.hit[slot] = H;
+		}
+	}
+	// a ray whose answer is not proven goes to the exact traversal (k_intersect_odd)
+	const bool again = active && doubt;
+	if (__ballot(again)) {
+		const uint32_t qd = ray_queue_index(par, kDoubtRays, shard);
+		const uint32_t at = queue_push(again, &a.cnt->n_ray[qd]);
+		if (again)
+			a.q_ray[(size_t)qd * a.shard_cap + at] = slot;
+	}
+	if (__ballot(onward)) {
+		const bool tame = a.tree.tame != 0 && ray_is_tame(next_ray);
+		const uint32_t qb = ray_queue_index(par, kBounceRays, shard), qo = ray_queue_index(par, kOddRays, shard);
+		const uint32_t at = queue_push(onward && tame, &a.cnt->n_ray[qb]);
+		if (onward && tame) {
+			float4 *e = a.q_bounce + 2 * (((size_t)par * kShards + shard) * a.shard_cap + at);
+			e[0] = make_float4(next_ray.o.x, next_ray.o.y, next_ray.o.z, next_ray.d.x);
+			e[1] = make_float4(next_ray.d.y, next_ray.d.z, __uint_as_float(slot), 0.f);
+		}
+		const uint32_t ato = queue_push(onward && !tame, &a.cnt->n_ray[qo]);
+		if (onward && !tame)
+			a.q_ray[(size_t)qo * a.shard_cap + ato] = slot;
 	}
 	if (COUNT)
 		count_flush(a.cnt, wc);
@@ -1441,7 +1514,18 @@ void launch_intersect(hipStream_t s, const RenderArgs &a, int par, int depth, bo
 		hipLaunchKernelGGL(k_intersect_leafwise<true>, dim3(leafwise_blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);
 	else if (a.leafwise)
 		hipLaunchKernelGGL(k_intersect_leafwise<false>, dim3(leafwise_blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);
-	else if (a.wide_cap) {
+	else if (a.wide_cap && a.camera_cells) {
+		// camera rays from their cells' lists first (their bounce rays may join this step's), then the bounce rays' walk
+		const unsigned camera_blocks = kShards * (a.grid_cap / kBlock), bounce_blocks = blocks - camera_blocks;
+		const size_t lds = stack_bytes(std::max(depth, (int)a.wide_cap));
+		if (count) {
+			hipLaunchKernelGGL(k_camera_cells<true>, dim3(camera_blocks), dim3(kBlock), 0, s, a, par);
+			hipLaunchKernelGGL((k_intersect<true, true>), dim3(bounce_blocks), dim3(kBlock), lds, s, a, par, depth);
+		} else {
+			hipLaunchKernelGGL(k_camera_cells<false>, dim3(camera_blocks), dim3(kBlock), 0, s, a, par);
+			hipLaunchKernelGGL((k_intersect<false, true>), dim3(bounce_blocks), dim3(kBlock), lds, s, a, par, depth);
+		}
+	} else if (a.wide_cap) {
 		// one LDS column per lane serves the exact traversal's stack (camera rays) and the certified walk
 		const size_t lds = stack_bytes(std::max(depth, (int)a.wide_cap));
 		static const bool split = getenv("RTA_SPLIT_INTERSECT") != nullptr;      // measurement: the two parts as two launches

@@ -102,7 +102,9 @@ struct RenderArgs {
 	// slot's camera ray (its place on the image plane, -1: none), cell_start[cell] .. cell_start[cell + 1] are
 	// the cell's entries of cell_list (triangle numbers)
 	uint32_t camera_cells;
+	uint32_t shade_first_hit;      //   and those that hit are shaded where they are answered (k_camera_cells; scenes without lights)
 	const uint32_t *cell_start, *cell_list;
+	const unsigned long long *cell_keys;      // per entry: cell << 32 | bits of the nearest t the entry's triangle can be hit at
 	int32_t cell_w, cell_h;        // the map: the frame and kSkyBorder cells around it
 	// occlusion queue, 3 per entry: (origin, limit) (direction, slot) (radiance, -)
 	float4 *shadow;
@@ -160,12 +162,16 @@ void launch_sky_map(hipStream_t s, const TreeRef &tree, uint32_t n_pairs, const 
                     uint32_t height, uint8_t *cover, float *sky_map);
 // cells.hip: per-cell triangle lists of a pinhole camera.  counts, starts: map_w x map_h + 1 words each; `span`: no admitted
 // origin is further from a vertex (WideTree::span).  The count pass leaves the number of entries in starts[map_w x map_h];
-// the fill pass writes them into `list`.
+// the fill pass writes them into `list`, nearest first.
 size_t cell_scan_temp_bytes(size_t n);
 hipError_t launch_cell_count(hipStream_t s, const TreeRef &tree, uint32_t n_wide, const Projection &pr, double span, int map_w,
                              int map_h, uint32_t *counts, uint32_t *starts, void *temp, size_t temp_bytes);
+size_t cell_sort_temp_bytes(size_t entries);
+// list, keys: the cells' entries nearest first; keys[k] = cell number << 32 | bits of the least t at which the test can accept
+// list[k] for a ray through the cell
 hipError_t launch_cell_fill(hipStream_t s, const TreeRef &tree, uint32_t n_wide, const Projection &pr, double span, int map_w,
-                            int map_h, uint32_t *counts, const uint32_t *starts, uint32_t *list);
+                            int map_h, uint32_t *counts, const uint32_t *starts, size_t entries, uint32_t *list_unsorted,
+                            unsigned long long *keys_unsorted, uint32_t *list, unsigned long long *keys, void *temp, size_t temp_bytes);
 void launch_intersect(hipStream_t s, const RenderArgs &a, int par, int depth, bool count);
 void launch_shadow(hipStream_t s, const RenderArgs &a, int depth, bool count);
 void launch_sum_blocks(hipStream_t s, const float4 *partial, const int32_t *pixels, uint32_t n_pad, uint32_t n_blocks,

@@ -3,7 +3,8 @@
 //
 // The list holds every triangle that the reference's HitTriangle (src/main.cpp:250-279) can accept
 // for a ray through the cell, so testing the list - with the reference's own arithmetic - does
-// what step 1 of the walk's proof asks of the walk: every accepted triangle is tested.  Steps 2
+// what step 1 of the walk's proof asks of the walk: every accepted triangle that can be as near
+// as the answer is tested.  Steps 2
 // and 3 (no tie; the hit triangle's leaf box passes the reference's box test) are the walk's own
 // certify().  A ray without a cell, or one the wide tree's padding was not computed for, is left
 // in doubt like a ray the walk gives up on.
@@ -16,7 +17,8 @@ namespace rta {
 // Must be reached by every lane of the wave (`active`: the lane holds a ray).
 template <bool COUNT>
 RTA_DEV void closest_from_cell(const DeviceTree &tree, const bool active, const Ray &ray, const int32_t cell,
-                               const uint32_t *cell_start, const uint32_t *cell_list, HitRec &hit, bool &doubt, WorkCount &work)
+                               const uint32_t *cell_start, const uint32_t *cell_list, const unsigned long long *cell_keys,
+                               HitRec &hit, bool &doubt, WorkCount &work)
 {
 	WideTraversal<COUNT, false> tr;
 	tr.rest(0);
@@ -31,8 +33,12 @@ RTA_DEV void closest_from_cell(const DeviceTree &tree, const bool active, const 
 			end = cell_start[cell + 1];
 		}
 	}
-	// one triangle per lane and trip, for as long as some lane has one left
+	// One triangle per lane and trip, for as long as some lane has one left.  The entries come nearest first
+	// by the least distance at which each can be hit at all (the low word of its key): once that lies beyond
+	// the nearest hit so far, the rest of the list cannot change the answer nor tie with it.
 	while (__ballot(k < end)) {
+		if (k < end && __uint_as_float((uint32_t)cell_keys[k]) > tr.best)
+			k = end;
 		if (k < end) {
 			const uint32_t i = cell_list[k++];
 			if (COUNT) work.tri++;

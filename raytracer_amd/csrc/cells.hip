@@ -1,20 +1,31 @@
 // Per-cell triangle lists for a pinhole camera's rays.
 //
 // All camera rays start at one point, so which triangles a camera ray can hit is decided by where
-// it crosses the image plane.  Once per view, every triangle of the wide tree is drawn onto the
-// pixel-sized cells of the image plane (the frame and kSkyBorder cells around it) - its projected
-// outline widened by what the reference's arithmetic can add - and every cell gets the list of the
-// triangles that touch it.  A camera ray is then answered by testing the triangles of its cell with
-// the reference's own HitTriangle arithmetic (src/main.cpp:250-279), no tree involved, and certified
-// as in traverse_wide.hpp: the list takes the place of step 1 of the proof there.
+// it crosses the image plane.  Once per view, every triangle that some leaf of the reference's tree
+// holds is drawn onto the pixel-sized cells of the image plane (the frame and kSkyBorder cells around
+// it) - its projected outline widened by what the reference's arithmetic can add - and every cell
+// gets the list of the triangles that touch it.  A camera ray is then answered by testing the
+// triangles of its cell with the reference's own HitTriangle arithmetic (src/main.cpp:250-279), no
+// tree involved, and certified as in traverse_wide.hpp: the list takes the place of step 1 of the
+// proof there.
 //
-// Why the list is complete.  Let the reference's HitTriangle accept triangle p for an admitted ray
-// (|origin - any vertex| <= S, |direction| <= kWideMaxDir, components of ordinary magnitude).  By the
-// derivation in wide_tree.cpp the exact intersection X of the ray's line with p's plane lies within
-//     rho = 16.02e4 u |d| E^2 (S + E) + 2uE,   u = 2^-24, E = p's longest stored edge vector,
-// of p.  X lies on the ray's line, in front of the camera (every point within rho of p is, checked
-// below), so X is seen at the ray's own point on the image plane.  Seen from the pinhole, a point
-// within rho of a point P of the triangle lands within (rx, ry) pixels of P's image, where with
+// Why the list is complete.  Let HitTriangle accept triangle p for a camera ray: tame components,
+// |d| <= dmax = 1.00011 (the rays are normalised), computed determinant D with |D| >= 1e-4 (the test
+// rejects smaller ones).  With u = 2^-24, E = the longer of p's stored edge vectors and
+// S >= |o - vertex| for p's vertices, the test's three numerators are within 8u |d| E (S + E) resp.
+// 8u E^2 (S + |t d|) of their exact values and D within delta = 8u |d| E^2 of the exact determinant
+// D* = -d . (e0 x e1) (the roundings are counted in wide_tree.cpp), hence the exact intersection X
+// of the ray's line with p's plane lies within
+//     rho = 16.02 u dmax E^2 (S + E) / |D| + 2uE
+// of p.  The walk's boxes have to take |D| = 1e-4, the worst any ray can do; here the ray's cell is
+// known, and with it a lower bound of |D*|: d . n is q . n / |q| for the point q where the ray crosses
+// the image plane, q . n is linear in q and |q| convex, so over a cell (widened by the margin below)
+// |D*| >= min over its corners |q . n| / max over its corners |q| if q . n keeps its sign, and
+// |D| >= max(1e-4, that (1 - 1e-6) - delta).  A wall seen from in front gets a rho of a thousandth of a
+// pixel instead of a third of the room.
+// X lies on the ray's line, in front of the camera (every point within rho of p is, checked below),
+// so X is seen at the ray's own point on the image plane.  Seen from the pinhole, a point within rho
+// of a point P of the triangle lands within (rx, ry) pixels of P's image, where with
 // x = h a / z - c (a = (P - o).du / du2, z = (P - o).n, see Projection)
 //     rx = rho (|h| / |du| + max |x + c| |n|) / (min |z| - rho |n|)
 // and ry likewise: the maxima and minima over the triangle are taken at its vertices.  The ray's
@@ -26,11 +37,10 @@
 //
 // Nearest first.  Every entry carries a lower bound of the distance at which the test can accept its
 // triangle for a ray through the cell, and a cell's entries are sorted by it, so that the tests can stop at
-// the first entry whose bound lies beyond the nearest hit so far.  A camera ray's direction is normalised
-// (|d| within 1 +- 1e-6), so its parameter at X is |X - o| up to that factor, and X lies at least
-// (depth - rho) sec(theta) from the pinhole: depth = the least distance of the triangle's vertices from the
-// pinhole along the camera's axis, theta = the least angle to that axis of any ray through the cell; the
-// computed t lies within dt = 16.02e4 u E^2 (S + E) + u t of the parameter at X (wide_tree.cpp).
+// the first entry whose bound lies beyond the nearest hit so far.  The ray's parameter at X is |X - o| / |d|,
+// and X lies at least (depth - rho) sec(theta) from the pinhole: depth = the least distance of the triangle's
+// vertices from the pinhole along the camera's axis, theta = the least angle to that axis of any ray through
+// the cell; the computed t lies within dt = 16.02 u E^2 (S + E) / |D| + u t of the parameter at X.
 #include "kernels.hpp"
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -41,22 +51,26 @@ namespace rta {
 namespace {
 
 constexpr int kCellBlock = 256;
+constexpr double kCameraMaxDir = 1.00011;      // k_camera_cells admits |d|^2 <= 1.0002
 
 struct Outline {
 	double x[3], y[3];      // projected vertices, pixel coordinates
-	double widen;           // pixels
-	bool everywhere;        // no statement about this triangle: it joins every cell
 	bool edges;             // the three edge tests apply (a proper triangle on the image plane)
 	double mx[3], my[3];    // outward unit normals of the edges k -> k + 1
-	double depth;           // least distance of a point within rho of the triangle from the pinhole, along the camera's axis
-	double dt;              // see above (without the u t part)
+	double bx0, bx1, by0, by1;     // the projected vertices' bounding rectangle
+	double nrm[3];          // e0 x e1
+	double rho_num;         // rho = rho_num / |D| + two_ue
+	double two_ue;
+	double delta;           // the computed determinant lies within it of the exact one
+	double dt_num;          // dt = dt_num / |D| (+ u t)
+	double kx, ky;          // rx = rho kx / (z_min - rho n_len), ry likewise
+	double z_min, n_len;    // z_min = 0: no statement about this triangle (a vertex is not safely in front of the camera): it joins every cell
 	double ppx, ppy;        // where the camera's axis meets the image plane, pixel coordinates
 	double tan2_x, tan2_y;  // (a pixel's width, height / the image plane's distance)^2
-	int i0, i1, j0, j1;     // cells of the bounding rectangle, clipped to the map (empty when i1 < i0 or j1 < j0)
+	int i0, i1, j0, j1;     // cells that the outline can touch at its widest, clipped to the map (empty when i1 < i0 or j1 < j0)
 };
 
-__device__ Outline outline_of(const TreeRef &tree, const uint32_t prim, const Projection &pr, const double span,
-                              const int map_w, const int map_h)
+__device__ Outline outline_of(const TreeRef &tree, const uint32_t prim, const Projection &pr, const int map_w, const int map_h)
 {
 	Outline t;
 	const float4 *rec = tree.prims + kPrimQuads * (size_t)prim;
@@ -65,11 +79,13 @@ __device__ Outline outline_of(const TreeRef &tree, const uint32_t prim, const Pr
 	const double v[3][3] = {{(double)p0.x + p1.x, (double)p0.y + p1.y, (double)p0.z + p1.z},
 	                        {(double)p0.x + p2.x, (double)p0.y + p2.y, (double)p0.z + p2.z},
 	                        {(double)p0.x, (double)p0.y, (double)p0.z}};
-	const double e0 = sqrt((double)p1.x * p1.x + (double)p1.y * p1.y + (double)p1.z * p1.z);
-	const double e1 = sqrt((double)p2.x * p2.x + (double)p2.y * p2.y + (double)p2.z * p2.z);
-	const double edge = (e0 > e1 ? e0 : e1) * (1 + 1e-6);
+	const double e0[3] = {p1.x, p1.y, p1.z}, e1[3] = {p2.x, p2.y, p2.z};
+	const double l0 = sqrt(e0[0] * e0[0] + e0[1] * e0[1] + e0[2] * e0[2]), l1 = sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+	const double edge = (l0 > l1 ? l0 : l1) * (1 + 1e-6);
+	t.nrm[0] = e0[1] * e1[2] - e0[2] * e1[1];
+	t.nrm[1] = e0[2] * e1[0] - e0[0] * e1[2];
+	t.nrm[2] = e0[0] * e1[1] - e0[1] * e1[0];
 	const double u = 0x1p-24;
-	const double rho = (16.02e4 * u * (double)kWideMaxDir * edge * edge * (span + edge) + 2 * u * edge) * (1 + 1e-9);
 	double n_len = 0, du_len = sqrt(pr.du2), dv_len = sqrt(pr.dv2), cx = 0, cy = 0;
 	for (int k = 0; k < 3; k++) {
 		n_len += pr.n[k] * pr.n[k];
@@ -80,17 +96,19 @@ __device__ Outline outline_of(const TreeRef &tree, const uint32_t prim, const Pr
 	cx /= pr.du2;
 	cy /= pr.dv2;
 	const double h_abs = pr.h < 0 ? -pr.h : pr.h;
-	t.everywhere = !(rho >= 0 && rho < 1e30);
-	double z_min = 1e300, xc_max = 0, yc_max = 0;
+	bool bad_vertex = false;
+	double z_min = 1e300, xc_max = 0, yc_max = 0, far = 0;
 	for (int c = 0; c < 3; c++) {
-		double w[3], z = 0;
+		double w[3], z = 0, w2 = 0;
 		for (int k = 0; k < 3; k++) {
 			w[k] = v[c][k] - pr.o[k];
 			z += w[k] * pr.n[k];
+			w2 += w[k] * w[k];
 		}
+		far = w2 > far ? w2 : far;
 		const double scale = pr.h / z;
 		if (!(scale > 0) || !(scale < 1e6))
-			t.everywhere = true;
+			bad_vertex = true;
 		double x = 0, y = 0;
 		for (int k = 0; k < 3; k++) {
 			const double p = pr.o[k] + w[k] * scale - pr.ul[k];
@@ -100,7 +118,7 @@ __device__ Outline outline_of(const TreeRef &tree, const uint32_t prim, const Pr
 		x /= pr.du2;
 		y /= pr.dv2;
 		if (!(x > -1e9 && x < 1e9 && y > -1e9 && y < 1e9))
-			t.everywhere = true;
+			bad_vertex = true;
 		t.x[c] = x;
 		t.y[c] = y;
 		const double za = z < 0 ? -z : z, xa = x + cx < 0 ? -(x + cx) : x + cx, ya = y + cy < 0 ? -(y + cy) : y + cy;
@@ -108,38 +126,40 @@ __device__ Outline outline_of(const TreeRef &tree, const uint32_t prim, const Pr
 		xc_max = xa > xc_max ? xa : xc_max;
 		yc_max = ya > yc_max ? ya : yc_max;
 	}
-	// every point within rho of the triangle must lie well in front of the camera
-	if (!(z_min > 2 * rho * n_len))
-		t.everywhere = true;
-	double widen = 0;
-	if (!t.everywhere) {
-		const double rx = rho * (h_abs / du_len + xc_max * n_len) / (z_min - rho * n_len);
-		const double ry = rho * (h_abs / dv_len + yc_max * n_len) / (z_min - rho * n_len);
-		widen = sqrt(rx * rx + ry * ry) * (1 + 1e-9) + pr.margin;
-		if (!(widen < 1e9))
-			t.everywhere = true;
-	}
-	t.widen = widen;
-	t.depth = t.everywhere ? 0 : (z_min / n_len - rho) * (1 - 1e-9);
-	t.dt = 16.02e4 * u * edge * edge * (span + edge) * (1 + 1e-9);
+	const double reach = sqrt(far) * (1 + 1e-9) + edge;      // S + E
+	t.rho_num = 16.02 * u * kCameraMaxDir * edge * edge * reach * (1 + 1e-9);
+	t.two_ue = 2 * u * edge;
+	t.delta = 8 * u * kCameraMaxDir * edge * edge * (1 + 1e-9);
+	t.dt_num = 16.02 * u * edge * edge * reach * (1 + 1e-9);
+	t.kx = h_abs / du_len + xc_max * n_len;
+	t.ky = h_abs / dv_len + yc_max * n_len;
+	t.z_min = z_min;
+	t.n_len = n_len;
 	t.ppx = -cx;
 	t.ppy = -cy;
 	const double plane = h_abs / n_len;
 	t.tan2_x = pr.du2 / (plane * plane);
 	t.tan2_y = pr.dv2 / (plane * plane);
-	double x0 = -1e9, x1 = 1e9, y0 = -1e9, y1 = 1e9;
+	t.bx0 = fmin(t.x[0], fmin(t.x[1], t.x[2]));
+	t.bx1 = fmax(t.x[0], fmax(t.x[1], t.x[2]));
+	t.by0 = fmin(t.y[0], fmin(t.y[1], t.y[2]));
+	t.by1 = fmax(t.y[0], fmax(t.y[1], t.y[2]));
 	t.edges = false;
-	if (!t.everywhere) {
-		x0 = fmin(t.x[0], fmin(t.x[1], t.x[2]));
-		x1 = fmax(t.x[0], fmax(t.x[1], t.x[2]));
-		y0 = fmin(t.y[0], fmin(t.y[1], t.y[2]));
-		y1 = fmax(t.y[0], fmax(t.y[1], t.y[2]));
-		// (and by more than the rounding of these few binary64 operations)
-		const double slack = 1e-9 * (fabs(x0) + fabs(x1) + fabs(y0) + fabs(y1) + 1);
-		t.widen = widen + slack;
-		x0 -= t.widen, x1 += t.widen, y0 -= t.widen, y1 += t.widen;
+	double x0 = -1e9, x1 = 1e9, y0 = -1e9, y1 = 1e9;      // (the whole map)
+	if (bad_vertex) {
+		t.z_min = 0;
+	} else {
+		// the widest the outline can get: at the least determinant the test lets pass
+		const double rho = t.rho_num * 1e4 + t.two_ue;
+		if (rho >= 0 && rho < 1e30 && z_min > 2 * rho * n_len) {
+			const double rx = rho * t.kx / (z_min - rho * n_len), ry = rho * t.ky / (z_min - rho * n_len);
+			// (and by more than the rounding of these few binary64 operations)
+			const double widest = sqrt(rx * rx + ry * ry) * (1 + 1e-9) + pr.margin + 1e-9 * (fabs(t.bx0) + fabs(t.bx1) + fabs(t.by0) + fabs(t.by1) + 1);
+			if (widest < 1e9)
+				x0 = t.bx0 - widest, x1 = t.bx1 + widest, y0 = t.by0 - widest, y1 = t.by1 + widest;
+		}
 		const double area2 = (t.x[1] - t.x[0]) * (t.y[2] - t.y[0]) - (t.x[2] - t.x[0]) * (t.y[1] - t.y[0]);
-		const double extent = (x1 - x0) + (y1 - y0);
+		const double extent = (t.bx1 - t.bx0) + (t.by1 - t.by0);
 		// a sliver has no usable edge normals: the rectangle alone serves it
 		if (fabs(area2) > 1e-9 * extent * extent && fabs(area2) > 1e-12) {
 			t.edges = true;
@@ -166,70 +186,123 @@ __device__ Outline outline_of(const TreeRef &tree, const uint32_t prim, const Pr
 	return t;
 }
 
-// may a camera ray through cell (ci, cj) of the map be one that the triangle's test accepts?
-__device__ bool touches(const Outline &t, const int ci, const int cj)
+// May a camera ray through cell (ci, cj) of the map be one that the triangle's test accepts?  If so, `nearest`
+// is a lower bound of the t the test can return for such a ray.
+__device__ bool touches(const Outline &t, const Projection &pr, const int ci, const int cj, float &nearest)
 {
-	if (!t.edges)
+	nearest = 0.f;
+	if (!(t.z_min > 0))
 		return true;
-	const double ccx = (double)(ci - kSkyBorder) + .5, ccy = (double)(cj - kSkyBorder) + .5;
-	for (int k = 0; k < 3; k++) {
-		// the cell's nearest point to the edge's line, measured along the outward normal
-		const double s = t.mx[k] * (ccx - t.x[k]) + t.my[k] * (ccy - t.y[k]) - .5 * (fabs(t.mx[k]) + fabs(t.my[k]));
-		if (s > t.widen)
-			return false;
+	// the least |determinant| of a ray through the cell, widened by the margin
+	const double cx0 = (double)(ci - kSkyBorder) - pr.margin, cx1 = (double)(ci - kSkyBorder) + 1 + pr.margin;
+	const double cy0 = (double)(cj - kSkyBorder) - pr.margin, cy1 = (double)(cj - kSkyBorder) + 1 + pr.margin;
+	double g_least = 1e300, q_most = 0;
+	int positive = 0, negative = 0;
+	for (int c = 0; c < 4; c++) {
+		const double x = (c & 1) ? cx1 : cx0, y = (c & 2) ? cy1 : cy0;
+		double g = 0, q2 = 0;
+		for (int k = 0; k < 3; k++) {
+			const double q = (pr.ul[k] - pr.o[k]) + x * pr.du[k] + y * pr.dv[k];
+			g += q * t.nrm[k];
+			q2 += q * q;
+		}
+		positive += g > 0;
+		negative += g < 0;
+		g = g < 0 ? -g : g;
+		g_least = g < g_least ? g : g_least;
+		q_most = q2 > q_most ? q2 : q_most;
+	}
+	double det = 1e-4;
+	if ((positive == 4 || negative == 4) && q_most > 0) {
+		const double seen = g_least / sqrt(q_most) * (1 - 1e-6) - t.delta;
+		det = seen > det ? seen : det;
+	}
+	const double rho = t.rho_num / det + t.two_ue;
+	if (!(rho >= 0) || !(t.z_min > 2 * rho * t.n_len))
+		return true;
+	const double rx = rho * t.kx / (t.z_min - rho * t.n_len), ry = rho * t.ky / (t.z_min - rho * t.n_len);
+	const double slack = 1e-9 * (fabs(t.bx0) + fabs(t.bx1) + fabs(t.by0) + fabs(t.by1) + 1);
+	const double widen = sqrt(rx * rx + ry * ry) * (1 + 1e-9) + pr.margin + slack;
+	if (!(widen < 1e9))
+		return true;
+	const double x0 = (double)(ci - kSkyBorder), y0 = (double)(cj - kSkyBorder);
+	if (x0 + 1 < t.bx0 - widen || x0 > t.bx1 + widen || y0 + 1 < t.by0 - widen || y0 > t.by1 + widen)
+		return false;
+	if (t.edges)
+		for (int k = 0; k < 3; k++) {
+			// the cell's nearest point to the edge's line, measured along the outward normal
+			const double s = t.mx[k] * (x0 + .5 - t.x[k]) + t.my[k] * (y0 + .5 - t.y[k]) - .5 * (fabs(t.mx[k]) + fabs(t.my[k]));
+			if (s > widen)
+				return false;
+		}
+	// the point of the cell (widened by a pixel: far more than the margin) nearest to the camera's axis
+	const double ax0 = x0 - 1, ax1 = x0 + 2, ay0 = y0 - 1, ay1 = y0 + 2;
+	const double dx = t.ppx < ax0 ? ax0 - t.ppx : (t.ppx > ax1 ? t.ppx - ax1 : 0), dy = t.ppy < ay0 ? ay0 - t.ppy : (t.ppy > ay1 ? t.ppy - ay1 : 0);
+	const double sec = sqrt(1 + dx * dx * t.tan2_x + dy * dy * t.tan2_y);
+	const double bound = ((t.z_min / t.n_len - rho) * sec / kCameraMaxDir * (1 - 2e-6) - t.dt_num / det) * (1 - 1e-6);
+	if (bound > 0) {
+		float f = (float)bound;
+		if ((double)f > bound)
+			f = __uint_as_float(__float_as_uint(f) - 1);      // (positive: the next float down)
+		nearest = f;
 	}
 	return true;
 }
 
-// lower bound of the t that HitTriangle can return for the triangle and a camera ray through the cell
-__device__ float nearest_t(const Outline &t, const int ci, const int cj)
-{
-	if (t.everywhere || !(t.depth > 0))
-		return 0.f;
-	// the point of the cell (widened by a pixel: far more than the margin) nearest to the camera's axis
-	const double x0 = (double)(ci - kSkyBorder) - 1, x1 = x0 + 3, y0 = (double)(cj - kSkyBorder) - 1, y1 = y0 + 3;
-	const double dx = t.ppx < x0 ? x0 - t.ppx : (t.ppx > x1 ? t.ppx - x1 : 0), dy = t.ppy < y0 ? y0 - t.ppy : (t.ppy > y1 ? t.ppy - y1 : 0);
-	const double sec = sqrt(1 + dx * dx * t.tan2_x + dy * dy * t.tan2_y);
-	const double bound = (t.depth * sec * (1 - 2e-6) - t.dt) * (1 - 1e-6);
-	if (!(bound > 0))
-		return 0.f;
-	float f = (float)bound;
-	if ((double)f > bound)
-		f = __uint_as_float(__float_as_uint(f) - 1);      // (positive: the next float down)
-	return f;
-}
-
-// One wave per child reference of a wide node (gridDim.y waves for big outlines); FILL: the second pass,
-// which writes the triangle and its key - cell number, then the bits of nearest_t - into the lists whose
-// lengths the first pass counted.
-template <bool FILL>
-__global__ __launch_bounds__(kCellBlock) void k_cell_lists(const TreeRef tree, const uint32_t n_wide, const Projection pr,
-                                                           const double span, const int map_w, const int map_h,
-                                                           uint32_t *counts, const uint32_t *starts, uint32_t *list,
-                                                           unsigned long long *keys)
+// One wave per triangle (gridDim.y waves for big outlines): BY_PRIMS, per primitive record that is a triangle in
+// some leaf of the reference's tree (TreeRef::leaf_boxes marks those); otherwise per child reference of a wide
+// node, which are the same triangles.  FILL: the second pass, which writes the triangle and its key - cell
+// number, then the bits of the bound - into the lists whose lengths the first pass counted.
+template <bool FILL, bool BY_PRIMS>
+__global__ __launch_bounds__(kCellBlock) void k_cell_lists(const TreeRef tree, const uint32_t n_items, const Projection pr,
+                                                           const int map_w, const int map_h, uint32_t *counts,
+                                                           const uint32_t *starts, uint32_t *list, unsigned long long *keys)
 {
 	const uint32_t item = blockIdx.x * (kCellBlock / 64) + threadIdx.x / 64, lane = threadIdx.x & 63;
-	if (item >= 4 * n_wide)
+	if (item >= n_items)
 		return;
-	const uint32_t ref = reinterpret_cast<const uint32_t *>(tree.wide + 4 * (size_t)(item >> 2) + 3)[item & 3];
-	if (ref == kWideNone || !(ref & kWideLeaf))
-		return;
-	const uint32_t prim = ref & ~kWideLeaf;
-	const Outline t = outline_of(tree, prim, pr, span, map_w, map_h);
+	uint32_t prim;
+	if (BY_PRIMS) {
+		prim = item;
+		if ((__float_as_uint(tree.prims[kPrimQuads * (size_t)prim].w) & 1u) || tree.leaf_boxes[2 * (size_t)prim].w != 1.f)
+			return;           // a sphere (tested for every ray), or in no leaf
+	} else {
+		const uint32_t ref = reinterpret_cast<const uint32_t *>(tree.wide + 4 * (size_t)(item >> 2) + 3)[item & 3];
+		if (ref == kWideNone || !(ref & kWideLeaf))
+			return;
+		prim = ref & ~kWideLeaf;
+	}
+	const Outline t = outline_of(tree, prim, pr, map_w, map_h);
 	if (t.i1 < t.i0 || t.j1 < t.j0)
 		return;
 	const uint32_t w = (uint32_t)(t.i1 - t.i0 + 1), n = w * (uint32_t)(t.j1 - t.j0 + 1);
 	for (uint32_t k = lane + 64 * blockIdx.y; k < n; k += 64 * gridDim.y) {
 		const int ci = t.i0 + (int)(k % w), cj = t.j0 + (int)(k / w);
-		if (!touches(t, ci, cj))
+		float nearest;
+		if (!touches(t, pr, ci, cj, nearest))
 			continue;
 		const size_t cell = (size_t)cj * map_w + ci;
 		const uint32_t at = atomicAdd(&counts[cell], 1u);
 		if (FILL) {
 			list[starts[cell] + at] = prim;
-			keys[starts[cell] + at] = ((unsigned long long)cell << 32) | __float_as_uint(nearest_t(t, ci, cj));
+			keys[starts[cell] + at] = ((unsigned long long)cell << 32) | __float_as_uint(nearest);
 		}
 	}
+}
+
+template <bool FILL>
+void launch_lists(hipStream_t s, const TreeRef &tree, uint32_t n_wide, uint32_t n_prims, const Projection &pr, int map_w, int map_h,
+                  uint32_t *counts, const uint32_t *starts, uint32_t *list, unsigned long long *keys)
+{
+	const bool by_prims = tree.wide == nullptr;
+	const uint32_t items = by_prims ? n_prims : 4 * n_wide;
+	// (a scene of a few triangles can have triangles that fill the frame; a scene of many has waves enough)
+	const unsigned waves_per_item = items < (1u << 12) ? 64 : (items < (1u << 16) ? 4 : 1);
+	const dim3 grid((items + kCellBlock / 64 - 1) / (kCellBlock / 64), waves_per_item);
+	if (by_prims)
+		hipLaunchKernelGGL((k_cell_lists<FILL, true>), grid, dim3(kCellBlock), 0, s, tree, items, pr, map_w, map_h, counts, starts, list, keys);
+	else
+		hipLaunchKernelGGL((k_cell_lists<FILL, false>), grid, dim3(kCellBlock), 0, s, tree, items, pr, map_w, map_h, counts, starts, list, keys);
 }
 
 }  // namespace
@@ -242,22 +315,14 @@ size_t cell_scan_temp_bytes(size_t n)
 	return bytes;
 }
 
-static dim3 cell_grid(uint32_t n_wide)
-{
-	// (a scene of a few triangles can have triangles that fill the frame; a scene of millions has waves enough)
-	const unsigned waves_per_leaf = n_wide < (1u << 14) ? 16 : 1;
-	return dim3((4 * n_wide + kCellBlock / 64 - 1) / (kCellBlock / 64), waves_per_leaf);
-}
-
-hipError_t launch_cell_count(hipStream_t s, const TreeRef &tree, uint32_t n_wide, const Projection &pr, double span, int map_w,
+hipError_t launch_cell_count(hipStream_t s, const TreeRef &tree, uint32_t n_wide, uint32_t n_prims, const Projection &pr, int map_w,
                              int map_h, uint32_t *counts, uint32_t *starts, void *temp, size_t temp_bytes)
 {
 	const size_t n = (size_t)map_w * map_h + 1;
 	hipError_t e = hipMemsetAsync(counts, 0, n * sizeof(uint32_t), s);
 	if (e != hipSuccess)
 		return e;
-	hipLaunchKernelGGL(k_cell_lists<false>, cell_grid(n_wide), dim3(kCellBlock), 0, s, tree, n_wide, pr, span, map_w, map_h, counts,
-	                   (const uint32_t *)nullptr, (uint32_t *)nullptr, (unsigned long long *)nullptr);
+	launch_lists<false>(s, tree, n_wide, n_prims, pr, map_w, map_h, counts, nullptr, nullptr, nullptr);
 	// starts[cell] = entries before the cell's; starts[cells] = all entries
 	return rocprim::exclusive_scan(temp, temp_bytes, counts, starts, 0u, n, rocprim::plus<uint32_t>(), s);
 }
@@ -271,7 +336,7 @@ size_t cell_sort_temp_bytes(size_t entries)
 	return bytes;
 }
 
-hipError_t launch_cell_fill(hipStream_t s, const TreeRef &tree, uint32_t n_wide, const Projection &pr, double span, int map_w,
+hipError_t launch_cell_fill(hipStream_t s, const TreeRef &tree, uint32_t n_wide, uint32_t n_prims, const Projection &pr, int map_w,
                             int map_h, uint32_t *counts, const uint32_t *starts, size_t entries, uint32_t *list_unsorted,
                             unsigned long long *keys_unsorted, uint32_t *list, unsigned long long *keys, void *temp, size_t temp_bytes)
 {
@@ -279,8 +344,7 @@ hipError_t launch_cell_fill(hipStream_t s, const TreeRef &tree, uint32_t n_wide,
 	hipError_t e = hipMemsetAsync(counts, 0, n * sizeof(uint32_t), s);
 	if (e != hipSuccess)
 		return e;
-	hipLaunchKernelGGL(k_cell_lists<true>, cell_grid(n_wide), dim3(kCellBlock), 0, s, tree, n_wide, pr, span, map_w, map_h, counts,
-	                   starts, list_unsorted, keys_unsorted);
+	launch_lists<true>(s, tree, n_wide, n_prims, pr, map_w, map_h, counts, starts, list_unsorted, keys_unsorted);
 	if ((e = hipGetLastError()) != hipSuccess || entries == 0)
 		return e;
 	// by cell, then nearest first (the cells' entries are contiguous already: `starts` stays valid)

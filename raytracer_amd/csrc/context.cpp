@@ -144,7 +144,7 @@ TreeRef tree_of(const rta_context *ctx)
 	memcpy(t.wide_center, ctx->wide_center, 12);
 	t.wide_reach2 = ctx->wide_reach2;
 	t.wide_index_mask = ctx->wide_index_mask;
-	t.n_loose = ctx->have_wide ? ctx->n_loose : 0u;
+	t.n_loose = ctx->have_leaf_boxes ? ctx->n_loose : 0u;
 	t.loose = ctx->loose.as<const uint32_t>();
 	t.wide_index_bits = (uint32_t)__builtin_popcount(ctx->wide_index_mask);
 	// with fewer than 11 bits left for the distance, a float's leading bits say too little
@@ -484,9 +484,18 @@ int rta_upload_scene(rta_context *ctx, const rta_scene_desc *desc)
 		return rc;
 	// the second tree, for the certified traversal
 	ctx->have_wide = false;
+	ctx->have_leaf_boxes = false;
 	WideTree wide = build_wide_tree(*desc, f.tame);
+	if (wide.certifiable) {
+		// what certifies an answer found without the reference's tree: by the walk, or from a camera's cell lists
+		if ((rc = upload_vec(ctx, ctx->leaf_boxes, wide.leaf_boxes)))
+			return rc;
+		ctx->n_loose = (uint32_t)wide.spheres.size();
+		if (!wide.spheres.empty() && (rc = upload_vec(ctx, ctx->loose, wide.spheres)))
+			return rc;
+	}
 	if (wide.enabled) {
-		if ((rc = upload_vec(ctx, ctx->wide_nodes, wide.nodes)) || (rc = upload_vec(ctx, ctx->leaf_boxes, wide.leaf_boxes)))
+		if ((rc = upload_vec(ctx, ctx->wide_nodes, wide.nodes)))
 			return rc;
 		memcpy(ctx->wide_center, wide.center, 12);
 		ctx->wide_reach2 = wide.reach * wide.reach * (1.f - 0x1p-20f);
@@ -495,12 +504,10 @@ int rta_upload_scene(rta_context *ctx, const rta_scene_desc *desc)
 		ctx->wide_index_mask = wide.index_mask;
 		ctx->wide_n_nodes = wide.n_nodes;
 		ctx->wide_span = wide.span;
-		ctx->n_loose = (uint32_t)wide.spheres.size();
-		if (!wide.spheres.empty() && (rc = upload_vec(ctx, ctx->loose, wide.spheres)))
-			return rc;
 	}
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // the staging vectors die with this call
 	ctx->have_wide = wide.enabled;
+	ctx->have_leaf_boxes = wide.certifiable;
 	if (getenv("RTA_WIDE_VERBOSE"))
 		fprintf(stderr, "wide tree: %s%s, %u nodes, depth %d, padding/extent %.4f, reach %g\n", wide.enabled ? "built" : "none: ",
 		        wide.why_not.c_str(), wide.n_nodes, wide.depth, wide.mean_pad_over_extent, wide.reach);
@@ -1019,13 +1026,15 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		base.hint = base.camera_walk && (hints ? atoi(hints) != 0 : true) ? ctx->hint.as<int32_t>() : nullptr;
 	}
 	// ... or are answered without any tree, from the triangle lists of their cells on the image plane (cells.hip),
-	// where samples can be placed on the image plane at all (the conditions of the sky map)
+	// where samples can be placed on the image plane at all (the conditions of the sky map) and an answer can be
+	// certified (the leaf boxes of the reference's tree are nested); with or without a wide tree
 	const int map_w = p->width + 2 * kSkyBorder, map_h = p->height + 2 * kSkyBorder;
 	const size_t n_cells = (size_t)map_w * (size_t)map_h;
 	bool want_cells = false;
 	{
 		static const char *cells = getenv("RTA_CAMERA_CELLS");      // measurement
-		want_cells = base.camera_walk && with_sky_map && n_cells < ((size_t)1 << 30) && (cells ? atoi(cells) != 0 : true);
+		want_cells = !(camera->defocus_angle > 0.f) && with_sky_map && ctx->have_leaf_boxes && ctx->tame && !(p->flags & RTA_RENDER_EXACT_ONLY) &&
+		             n_cells < ((size_t)1 << 30) && (cells ? atoi(cells) != 0 : true);
 	}
 	// the walk's thresholds: idle lanes that make a wave draw new rays, lanes with a listed triangle (lanes with
 	// nothing else to do) that make it run the triangle test.  Measured on dragon.txt, camera and bounce rays:
@@ -1087,7 +1096,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		HIP_TRY_R(ctx->cell_counts.reserve((n_cells + 1) * 4));
 		HIP_TRY_R(ctx->cell_starts.reserve((n_cells + 1) * 4));
 		HIP_TRY_R(ctx->cell_temp.reserve(std::max<size_t>(temp_bytes, 16)));
-		HIP_TRY_R(launch_cell_count(s, base.tree, ctx->wide_n_nodes, projection, (double)ctx->wide_span, map_w, map_h,
+		HIP_TRY_R(launch_cell_count(s, base.tree, ctx->wide_n_nodes, (uint32_t)ctx->n_prims, projection, map_w, map_h,
 		                            ctx->cell_counts.as<uint32_t>(), ctx->cell_starts.as<uint32_t>(), ctx->cell_temp.ptr, temp_bytes));
 		uint32_t entries = 0;
 		HIP_TRY_R(hipMemcpyAsync(&entries, ctx->cell_starts.as<uint32_t>() + n_cells, 4, hipMemcpyDeviceToHost, s));
@@ -1099,7 +1108,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 			HIP_TRY_R(ctx->cell_keys.reserve(room * 8));
 			HIP_TRY_R(ctx->cell_unsorted.reserve(room * 12));      // keys, then triangle numbers
 			HIP_TRY_R(ctx->cell_temp.reserve(std::max<size_t>(sort_bytes, 16)));
-			HIP_TRY_R(launch_cell_fill(s, base.tree, ctx->wide_n_nodes, projection, (double)ctx->wide_span, map_w, map_h,
+			HIP_TRY_R(launch_cell_fill(s, base.tree, ctx->wide_n_nodes, (uint32_t)ctx->n_prims, projection, map_w, map_h,
 			                           ctx->cell_counts.as<uint32_t>(), ctx->cell_starts.as<uint32_t>(), entries,
 			                           reinterpret_cast<uint32_t *>(ctx->cell_unsorted.as<unsigned long long>() + room),
 			                           ctx->cell_unsorted.as<unsigned long long>(), ctx->cell_list.as<uint32_t>(),

@@ -848,6 +848,8 @@ __global__ __launch_bounds__(kBlock) void k_camera_cells(const RenderArgs a, con
 		const uint32_t qb = ray_queue_index(par, kBounceRays, shard), qo = ray_queue_index(par, kOddRays, shard);
 		const uint32_t at = queue_push(onward && tame, &a.cnt->n_ray[qb]);
 		if (onward && tame) {
+			if (a.leafwise)      // (the other traversal kernels find the slot number in the entry below)
+				a.q_ray[(size_t)qb * a.shard_cap + at] = slot;
 			float4 *e = a.q_bounce + 2 * (((size_t)par * kShards + shard) * a.shard_cap + at);
 			e[0] = make_float4(next_ray.o.x, next_ray.o.y, next_ray.o.z, next_ray.d.x);
 			e[1] = make_float4(next_ray.d.y, next_ray.d.z, __uint_as_float(slot), 0.f);
@@ -1510,21 +1512,25 @@ void launch_intersect(hipStream_t s, const RenderArgs &a, int par, int depth, bo
 	// (the same arithmetic as pulling_grid / per_kind in the kernels)
 	const unsigned blocks = kShards * ((a.grid_cap + kBlock * a.rays_per_lane - 1) / (kBlock * a.rays_per_lane)) + kShards * (a.grid_cap / kBlock);
 	const unsigned leafwise_blocks = 2 * kShards * (a.grid_cap / kBlock);
-	if (a.leafwise && count)
-		hipLaunchKernelGGL(k_intersect_leafwise<true>, dim3(leafwise_blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);
-	else if (a.leafwise)
-		hipLaunchKernelGGL(k_intersect_leafwise<false>, dim3(leafwise_blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);
-	else if (a.wide_cap && a.camera_cells) {
-		// camera rays from their cells' lists first (their bounce rays may join this step's), then the bounce rays' walk
-		const unsigned camera_blocks = kShards * (a.grid_cap / kBlock), bounce_blocks = blocks - camera_blocks;
-		const size_t lds = stack_bytes(std::max(depth, (int)a.wide_cap));
-		if (count) {
+	const unsigned camera_blocks = kShards * (a.grid_cap / kBlock);
+	if (a.camera_cells) {
+		// Camera rays from their cells' lists first (their bounce rays may join this step's); the traversal kernel
+		// that follows is launched without its workgroups for camera rays (they come last in every grid).
+		if (count)
 			hipLaunchKernelGGL(k_camera_cells<true>, dim3(camera_blocks), dim3(kBlock), 0, s, a, par);
-			hipLaunchKernelGGL((k_intersect<true, true>), dim3(bounce_blocks), dim3(kBlock), lds, s, a, par, depth);
-		} else {
+		else
 			hipLaunchKernelGGL(k_camera_cells<false>, dim3(camera_blocks), dim3(kBlock), 0, s, a, par);
-			hipLaunchKernelGGL((k_intersect<false, true>), dim3(bounce_blocks), dim3(kBlock), lds, s, a, par, depth);
-		}
+	}
+	if (a.leafwise && count)
+		hipLaunchKernelGGL(k_intersect_leafwise<true>, dim3(a.camera_cells ? camera_blocks : leafwise_blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);
+	else if (a.leafwise)
+		hipLaunchKernelGGL(k_intersect_leafwise<false>, dim3(a.camera_cells ? camera_blocks : leafwise_blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);
+	else if (a.wide_cap && a.camera_cells) {
+		const size_t lds = stack_bytes(std::max(depth, (int)a.wide_cap));
+		if (count)
+			hipLaunchKernelGGL((k_intersect<true, true>), dim3(blocks - camera_blocks), dim3(kBlock), lds, s, a, par, depth);
+		else
+			hipLaunchKernelGGL((k_intersect<false, true>), dim3(blocks - camera_blocks), dim3(kBlock), lds, s, a, par, depth);
 	} else if (a.wide_cap) {
 		// one LDS column per lane serves the exact traversal's stack (camera rays) and the certified walk
 		const size_t lds = stack_bytes(std::max(depth, (int)a.wide_cap));
@@ -1537,7 +1543,9 @@ void launch_intersect(hipStream_t s, const RenderArgs &a, int par, int depth, bo
 		} else
 			hipLaunchKernelGGL((k_intersect<false, true>), dim3(blocks), dim3(kBlock), lds, s, a, par, depth);
 	} else if (count)
-		hipLaunchKernelGGL((k_intersect<true, false>), dim3(blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);
+		hipLaunchKernelGGL((k_intersect<true, false>), dim3(a.camera_cells ? blocks - camera_blocks : blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);
+	else if (a.camera_cells)
+		hipLaunchKernelGGL((k_intersect<false, false>), dim3(blocks - camera_blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);
 	else if (getenv("RTA_SPLIT_INTERSECT")) {
 		hipLaunchKernelGGL((k_intersect<false, false, 1>), dim3(blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);
 		hipLaunchKernelGGL((k_intersect<false, false, 2>), dim3(blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);

@@ -45,7 +45,7 @@ struct TreeRef {
 	float box_lo[3], box_hi[3];
 	// The 4-wide tree of the certified traversal (traverse_wide.hpp, wide_tree.hpp); null when the scene has none.
 	const float4 *wide;          // 4 quads per node
-	const float4 *leaf_boxes;    // 2 quads per primitive: the box of its leaf in the reference's tree
+	const float4 *leaf_boxes;    // 2 quads per primitive: the box of its leaf in the reference's tree (lo, 1) (hi, 0); all 0: in no leaf
 	float wide_center[3];        // a ray may take the wide tree when |origin - wide_center|^2 <= wide_reach2
 	float wide_reach2;           //   and |direction|^2 <= kWideMaxDir^2
 	uint32_t wide_index_mask;    // 2^bits - 1: the bits of a child reference, stack or list entry that number the node or primitive
@@ -160,16 +160,17 @@ constexpr int kSkyBorder = 3;     // cells around the frame that the cover map i
 // cover: (width + 2 kSkyBorder) x (height + 2 kSkyBorder) bytes; sky_map: width x height floats
 void launch_sky_map(hipStream_t s, const TreeRef &tree, uint32_t n_pairs, const Projection &pr, uint32_t width,
                     uint32_t height, uint8_t *cover, float *sky_map);
-// cells.hip: per-cell triangle lists of a pinhole camera.  counts, starts: map_w x map_h + 1 words each; `span`: no admitted
-// origin is further from a vertex (WideTree::span).  The count pass leaves the number of entries in starts[map_w x map_h];
-// the fill pass writes them into `list`, nearest first.
+// cells.hip: per-cell triangle lists of a pinhole camera.  counts, starts: map_w x map_h + 1 words each.  The triangles are
+// those of the wide tree's n_wide nodes, or, for a scene without one (tree.wide == null), the n_prims primitive records
+// that are triangles in some leaf.  The count pass leaves the number of entries in starts[map_w x map_h]; the fill pass
+// writes them into `list`, nearest first.
 size_t cell_scan_temp_bytes(size_t n);
-hipError_t launch_cell_count(hipStream_t s, const TreeRef &tree, uint32_t n_wide, const Projection &pr, double span, int map_w,
+hipError_t launch_cell_count(hipStream_t s, const TreeRef &tree, uint32_t n_wide, uint32_t n_prims, const Projection &pr, int map_w,
                              int map_h, uint32_t *counts, uint32_t *starts, void *temp, size_t temp_bytes);
 size_t cell_sort_temp_bytes(size_t entries);
 // list, keys: the cells' entries nearest first; keys[k] = cell number << 32 | bits of the least t at which the test can accept
 // list[k] for a ray through the cell
-hipError_t launch_cell_fill(hipStream_t s, const TreeRef &tree, uint32_t n_wide, const Projection &pr, double span, int map_w,
+hipError_t launch_cell_fill(hipStream_t s, const TreeRef &tree, uint32_t n_wide, uint32_t n_prims, const Projection &pr, int map_w,
                             int map_h, uint32_t *counts, const uint32_t *starts, size_t entries, uint32_t *list_unsorted,
                             unsigned long long *keys_unsorted, uint32_t *list, unsigned long long *keys, void *temp, size_t temp_bytes);
 void launch_intersect(hipStream_t s, const RenderArgs &a, int par, int depth, bool count);

@@ -6,8 +6,8 @@
 // what step 1 of the walk's proof asks of the walk: every accepted triangle that can be as near
 // as the answer is tested.  Steps 2
 // and 3 (no tie; the hit triangle's leaf box passes the reference's box test) are the walk's own
-// certify().  A ray without a cell, or one the wide tree's padding was not computed for, is left
-// in doubt like a ray the walk gives up on.
+// certify().  A ray without a cell, or one the lists were not made for, is left in doubt like a
+// ray the walk gives up on.
 #pragma once
 
 #include "traverse_wide.hpp"
@@ -24,10 +24,25 @@ RTA_DEV void closest_from_cell(const DeviceTree &tree, const bool active, const 
 	tr.rest(0);
 	uint32_t k = 0, end = 0;
 	if (active) {
-		tr.start(tree, ray, 0);      // admits the ray and tests the spheres, which are in no list
-		tr.node = kWideNone;
-		if (cell < 0)
-			tr.doubt = true;
+		tr.ray = ray;
+		tr.rcp = mk(1.f / ray.d.x, 1.f / ray.d.y, 1.f / ray.d.z);
+		// the rays the lists were made for (cells.hip); NaNs fail the comparison
+		tr.doubt = !(ray_is_tame(ray) && norm2(ray.d) <= 1.0002f) || cell < 0;
+		// the spheres are in no list: each is tested, with the reference's own arithmetic
+		if (!tr.doubt)
+			for (uint32_t k = 0; k < tree.n_loose; k++) {
+				const uint32_t i = tree.loose[k];
+				const float4 *rec = tree.prims + kPrimQuads * (size_t)i;
+				const float4 p0 = rec[0], p1 = rec[1];
+				const float t = test_sphere(mk(p0.x, p0.y, p0.z), p1.x, ray);
+				if (t < tr.best) {
+					tr.best = t;
+					tr.prim = (int32_t)i;
+					tr.tie = false;
+				} else if (t == tr.best && t < FLT_MAX) {
+					tr.tie = true;
+				}
+			}
 		if (!tr.doubt) {
 			k = cell_start[cell];
 			end = cell_start[cell + 1];

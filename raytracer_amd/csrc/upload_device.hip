@@ -115,7 +115,7 @@ __global__ void k_expand(const Ref ref, int32_t begin, int32_t end, int32_t *ord
 		for (int32_t k = idx; k < idx + cnt; k++) {
 			if (atomicExch(&covered[k], k == idx + cnt - 1 ? 3u : 1u))
 				flags->bad = 1;      // the primitive belongs to two leaves
-			leaf_boxes[(size_t)k * 2] = make_float4(nb[0], nb[1], nb[2], 0.f);
+			leaf_boxes[(size_t)k * 2] = make_float4(nb[0], nb[1], nb[2], 1.f);      // (1: the primitive is in a leaf)
 			leaf_boxes[(size_t)k * 2 + 1] = make_float4(nb[3], nb[4], nb[5], 0.f);
 		}
 		extra[node] = 2 * cnt - 2;
@@ -850,6 +850,7 @@ int upload_scene_on_device(rta_context *ctx, const rta_scene_desc &d)
 
 	// the context's view of the scene, as rta_upload_scene's host path sets it
 	ctx->have_wide = wide.enabled;
+	ctx->have_leaf_boxes = wide.enabled;      // (this path certifies by the wide tree's conditions only)
 	if (wide.enabled) {
 		memcpy(ctx->wide_center, wide.center, 12);
 		ctx->wide_reach2 = wide.reach * wide.reach * (1.f - 0x1p-20f);

@@ -325,7 +325,7 @@ WideTree build_wide_tree(const rta_scene_desc &d, bool tame)
 			if (cnt > 0) {
 				for (int32_t p = idx; p < idx + cnt; p++) {
 					const float *g = d.prim_geom + (size_t)p * 9;
-					w.leaf_boxes[(size_t)p * 2] = make_float4(nb[0], nb[1], nb[2], 0);
+					w.leaf_boxes[(size_t)p * 2] = make_float4(nb[0], nb[1], nb[2], 1.f);      // (1: the primitive is in a leaf)
 					w.leaf_boxes[(size_t)p * 2 + 1] = make_float4(nb[3], nb[4], nb[5], 0);
 					if (d.prim_type[p] != RTA_PRIM_TRIANGLE) {
 						// a few spheres stay outside the tree and are tested for every ray
@@ -352,6 +352,9 @@ WideTree build_wide_tree(const rta_scene_desc &d, bool tame)
 		}
 	}
 
+	// the leaf boxes are complete and nested, the spheres few: answers can be certified (step 3 of the walk's
+	// proof) whether or not the scene gets a wide tree
+	w.certifiable = true;
 	if (covered.size() < 2)
 		return refuse("fewer than two triangles");
 

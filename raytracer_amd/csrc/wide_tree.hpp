@@ -17,6 +17,7 @@ namespace rta {
 
 struct WideTree {
 	bool enabled = false;
+	bool certifiable = false;         // leaf_boxes and spheres are complete (also where the tree itself was refused)
 	std::string why_not;              // when !enabled
 	// 4 x 16 bytes per node (one 64-byte line): twelve words of binary16 planes of the four
 	// children, relative to `center` and rounded outwards (lo.x lo.y lo.z hi.x hi.y hi.z, each as

@@ -68,12 +68,17 @@ def test_views_around_the_dragon(gpu):
         assert st["walked_rays"] > 0
 
 
-def test_a_camera_out_of_reach_keeps_the_tree(gpu):
-    """From three scene radii away the wide tree's padding does not cover the camera: its rays take the traversal that
-    replays the reference's order, the lists are not made."""
+def test_the_lists_do_not_need_the_wide_tree(gpu):
+    """The lists are made from the camera's own distances and each cell's own determinants, not from the wide tree's
+    padding: a camera three scene radii away, where the walk does not admit its rays, and cornell_box.txt, whose walls are
+    far too large for a wide tree at all (and whose sphere every camera ray tests), are served all the same."""
     base = open(f"{orc.SCENES}/dragon.txt").read()
     text = _with_render_block(base, camera="[-5.5 0.3 1.4]", width="96", height="64", samples="4", fov="25")
-    _render_both(gpu, text, seed=5, sps=2, expect_listed=False)
+    st = _render_both(gpu, text, seed=5, sps=2)
+    assert st["walked_rays"] > 0
+    text = orc.scene_variant("cornell_box.txt", 96, 72, 6)
+    st = _render_both(gpu, text, seed=6, sps=3)
+    assert st["walked_rays"] == 0 and st["shadow_rays"] > 0
 
 
 def _grid(n, z_of, x0=-1.0, x1=1.0):

@@ -70,7 +70,7 @@ WORKLOADS = {
     "dragon1080p": dict(scene="dragon.txt", width=1920, height=1080, spp=1024, survey_bytes_per_ray=691.0,
                         sps=8, cpu_spp=256, label="scenes/dragon.txt 1920x1080 1024spp"),
     "cornell1080p": dict(scene="cornell_box.txt", width=1920, height=1080, spp=256, survey_bytes_per_ray=764.0,
-                         sps=16, cpu_spp=64, label="scenes/cornell_box.txt 1920x1080 256spp"),
+                         sps=16, cpu_spp=64, label="scenes/cornell_box.txt 1920x1080 256spp", kernel="k_intersect_leafwise"),
     "dragon4k": dict(scene="dragon.txt", width=3840, height=2160, spp=4096, survey_bytes_per_ray=691.0,
                      sps=32, cpu_spp=64, label="scenes/dragon.txt 3840x2160 4096spp"),
     "soup10m": dict(tris=10_000_000, rays=64 * 1024 * 1024, cpu_rays=4 << 20,
@@ -448,9 +448,11 @@ def bench_render(args, env):
             "traced_fraction": main_run["traced"] / main_run["queries"],
             "retraced_rays_per_step": main_run["retraced"] / args.steps,
             "walked_rays_per_step": main_run["walked"] / args.steps,
-            "traversal": ("certified walk over the wide tree (bounce and shadow rays; camera rays where the camera lies within "
-                          "the tree's reach), order-replaying traversal for the rest"
-                          if main_run["walked"] else "order-replaying traversal (no wide tree for this scene, or --exact-only)"),
+            "traversal": ("certified walk over the wide tree (bounce and shadow rays), a pinhole camera's rays from the "
+                          "triangle lists of their cells on the image plane, order-replaying traversal for the few they leave over"
+                          if main_run["walked"] else
+                          "order-replaying traversal (no wide tree for this scene, or --exact-only); a pinhole camera's rays "
+                          "from the triangle lists of their cells on the image plane unless --exact-only"),
             "samples_per_s": m["samples_per_s"],
             "ms_per_step": m["ms_per_step"],
             "cold_ms_first_step": cold_ms,
@@ -479,14 +481,18 @@ def roofline_render(w, excl, count, m):
     it.  `excl`: stats of a render on ONE stream with every launch timed, so a
     launch's duration is its own; `count`: stats of a render that counted node
     visits and primitive tests on the device."""
-    traced = excl["rays"] - excl["early_rays"]
+    # The traversal kernel's own rays: what is traced at all, less the camera rays that k_camera_cells answers
+    # from the lists of their cells (its launches are timed apart, as are those of the few rays left over).
+    all_traced = excl["rays"] - excl["early_rays"]
+    traced = all_traced - excl["listed_rays"]
     launches = max(excl["intersect_launches"], 1)
     avg_ms = excl["intersect_ms"] / launches
     # algorithmic bytes of the queries that walked the tree, from the device's own counts of
     # what they visited (closest-hit and occlusion traversals share the counters)
-    queries = count["rays"] - count["early_rays"] + count["shadow_rays"]
-    alg_bytes = 64.0 * count["inner_visits"] + 36.0 * count["tri_tests"] + 16.0 * count["sph_tests"] + 40.0 * queries
-    closest_share = (count["rays"] - count["early_rays"]) / max(queries, 1)
+    queries = count["rays"] - count["early_rays"] - count["listed_rays"] + count["shadow_rays"]
+    alg_bytes = (64.0 * count["inner_visits"] + 36.0 * (count["tri_tests"] - count["cell_tests"]) + 16.0 * count["sph_tests"] +
+                 40.0 * queries)
+    closest_share = (count["rays"] - count["early_rays"] - count["listed_rays"]) / max(queries, 1)
     counted_per_ray = alg_bytes / max(queries, 1)
     rays_per_launch = traced / launches
     seconds = avg_ms * 1e-3
@@ -497,8 +503,11 @@ def roofline_render(w, excl, count, m):
     counted = counted_per_ray * rays_per_launch / seconds / 1e9 if seconds > 0 else 0.0
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-           "kernel": "k_intersect", "avg_launch_ms": avg_ms, "launches": launches,
+           "kernel": w.get("kernel", "k_intersect"), "avg_launch_ms": avg_ms, "launches": launches,
            "rays_per_launch": rays_per_launch,
+           "rays_of_the_kernel": "the closest-hit queries that are traced at all less the camera rays answered from their "
+                                 "cells' triangle lists by k_camera_cells (rta_stats.listed_rays), whose launches and those of "
+                                 "k_intersect_odd are timed apart (exclusive_pass)",
            "bytes_per_ray": w["survey_bytes_per_ray"],
            "bytes_per_ray_source": "64 B x inner visits + 36 B x triangle tests + 40 B with the reference traversal's "
                                    "visit counts averaged over every closest-hit query of the workload",
@@ -508,11 +517,15 @@ def roofline_render(w, excl, count, m):
                          "them from its caches (`traffic`, `hbm_frac_from_counters`, `l2_frac`), which is how the figure "
                          "can pass the HBM peak on a scene of a few kilobytes") if achieved > HBM_PEAK_GBS else None,
            "exclusive_pass": {"gpu_ms": excl["gpu_ms"], "intersect_ms": excl["intersect_ms"],
+                              "camera_cells_ms": excl["camera_ms"], "camera_cells_launches": excl["camera_launches"],
+                              "listed_camera_rays": excl["listed_rays"], "leftover_ms": excl["leftover_ms"],
                               "advance_ms": excl["advance_ms"], "shadow_ms": excl["shadow_ms"],
                               "advance_launches": excl["advance_launches"],
                               "traced_mrays_per_s_of_the_kernel_alone": traced / max(excl["intersect_ms"], 1e-9) / 1e3,
-                              "kernel_time_over_gpu_time": (excl["intersect_ms"] + excl["advance_ms"] +
-                                                            excl["shadow_ms"]) / max(excl["gpu_ms"], 1e-9)},
+                              "traced_mrays_per_s_of_the_closest_hit_launches": all_traced / max(
+                                  excl["intersect_ms"] + excl["camera_ms"] + excl["leftover_ms"], 1e-9) / 1e3,
+                              "kernel_time_over_gpu_time": (excl["intersect_ms"] + excl["camera_ms"] + excl["leftover_ms"] +
+                                                            excl["advance_ms"] + excl["shadow_ms"]) / max(excl["gpu_ms"], 1e-9)},
            # What the traced queries really visit, counted on the device in this run (closest-hit and
            # occlusion traversals share the counters).  The tree is L2-resident, so these bytes are
            # L2-served: priced against the aggregate L2 bandwidth, for the kernel alone and for the
@@ -532,10 +545,10 @@ def roofline_render(w, excl, count, m):
         with open(ppath) as f:
             pj = json.load(f)
         if pj.get("workload") == w["label"]:
-            k = pj["kernels"].get("k_intersect", {})
+            k = pj["kernels"].get(w.get("kernel", "k_intersect"), {})
             if "hbm_bytes_per_launch" in k:
-                # per traced ray from the profile, times this run's rays per launch
-                out["traffic"] = k["hbm_bytes_per_traced_ray"] * traced / launches
+                # per launch of the same workload in the profiled run
+                out["traffic"] = k["hbm_bytes_per_launch"]
                 out["traffic_over_algorithmic"] = out["traffic"] / per_launch if per_launch else None
                 out["hbm_frac_from_counters"] = out["traffic"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if avg_ms > 0 else None
             out["counters"] = {"source": "profiles/pmc_roofline.json (%s)" % pj.get("tag"), "kernels": pj["kernels"]}

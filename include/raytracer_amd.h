@@ -282,6 +282,11 @@ typedef struct {
 	uint64_t walked_rays;                   /* of `rays`: handed to the walk over the wide tree (0 for scenes without one) */
 	uint64_t listed_rays;                   /* of `rays`: a pinhole camera's rays answered from the triangle list of their cell
 	                                         * on the image plane, without a tree (retraced ones included) */
+	uint64_t cell_tests;                    /* RTA_RENDER_COUNT_WORK only: of tri_tests, those made for listed_rays */
+	double camera_ms, leftover_ms;          /* RTA_RENDER_TIME_KERNELS only: summed durations of the launches that answer
+	                                         * listed_rays, and of those that trace what the certified answers left over;
+	                                         * intersect_ms is the traversal kernel's alone */
+	uint64_t camera_launches;
 } rta_stats;
 
 /* The render loop.  Replaces src/main.cpp:657-714 (row loop, per-sample ray

@@ -71,7 +71,8 @@ class Stats(C.Structure):
                 ("gpu_ms", C.c_double), ("intersect_ms", C.c_double), ("shadow_ms", C.c_double),
                 ("intersect_launches", C.c_uint64), ("shadow_launches", C.c_uint64),
                 ("early_rays", C.c_uint64), ("advance_ms", C.c_double), ("advance_launches", C.c_uint64),
-                ("retraced_rays", C.c_uint64), ("walked_rays", C.c_uint64), ("listed_rays", C.c_uint64)]
+                ("retraced_rays", C.c_uint64), ("walked_rays", C.c_uint64), ("listed_rays", C.c_uint64),
+                ("cell_tests", C.c_uint64), ("camera_ms", C.c_double), ("leftover_ms", C.c_double), ("camera_launches", C.c_uint64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

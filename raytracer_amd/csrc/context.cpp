@@ -1057,7 +1057,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 
 	hipEvent_t ev_begin = nullptr, ev_mid = nullptr, ev_end = nullptr;
 	std::vector<hipEvent_t> ev_pool;        // begin/end pairs around timed launches
-	std::vector<int> ev_kind;               // 0 intersect, 1 shadow, 2 advance
+	std::vector<int> ev_kind;               // 0 intersect, 1 shadow, 2 advance, 3 camera cells, 4 the rays left over
 	auto cleanup = [&]() {
 		for (hipEvent_t e : {ev_begin, ev_mid, ev_end})
 			if (e)
@@ -1309,7 +1309,14 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 						HIP_TRY_R(timed(gs[g], 1, [&] {
 							launch_shadow(gs[g], a, ctx->stack_depth, count_work);
 						}));
-					HIP_TRY_R(timed(gs[g], 0, [&] { launch_intersect(gs[g], a, par, ctx->stack_depth, count_work); }));
+					if (time_kernels) {
+						// (the three launches of the closest-hit part, each with its own pair of events)
+						if (a.camera_cells)
+							HIP_TRY_R(timed(gs[g], 3, [&] { launch_intersect(gs[g], a, par, ctx->stack_depth, count_work, kStageCamera); }));
+						HIP_TRY_R(timed(gs[g], 0, [&] { launch_intersect(gs[g], a, par, ctx->stack_depth, count_work, kStageWalk); }));
+						HIP_TRY_R(timed(gs[g], 4, [&] { launch_intersect(gs[g], a, par, ctx->stack_depth, count_work, kStageOdd); }));
+					} else
+						launch_intersect(gs[g], a, par, ctx->stack_depth, count_work);
 				}
 				steps++;
 			}
@@ -1348,6 +1355,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 			st.retraced_rays += c.retraced;
 			st.walked_rays += c.walked;
 			st.listed_rays += c.listed;
+			st.cell_tests += c.cell_tests;
 		}
 		// all groups are idle here (synchronised above)
 		if (d_frame && n_owned)
@@ -1391,6 +1399,11 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		} else if (ev_kind[k] == 2) {
 			st.advance_ms += t;
 			st.advance_launches++;
+		} else if (ev_kind[k] == 3) {
+			st.camera_ms += t;
+			st.camera_launches++;
+		} else if (ev_kind[k] == 4) {
+			st.leftover_ms += t;
 		} else {
 			st.shadow_ms += t;
 			st.shadow_launches++;

@@ -843,6 +843,8 @@ __global__ __launch_bounds__(kBlock) void k_camera_cells(const RenderArgs a, con
 		if (again)
 			a.q_ray[(size_t)qd * a.shard_cap + at] = slot;
 	}
+	if (COUNT && wc.tri)
+		atomicAdd(&a.cnt->cell_tests, (unsigned long long)wc.tri);
 	if (__ballot(onward)) {
 		const bool tame = a.tree.tame != 0 && ray_is_tame(next_ray);
 		const uint32_t qb = ray_queue_index(par, kBounceRays, shard), qo = ray_queue_index(par, kOddRays, shard);
@@ -1507,13 +1509,13 @@ void launch_sky_map(hipStream_t s, const TreeRef &tree, uint32_t n_pairs, const 
 	                   (int)height, sky_map);
 }
 
-void launch_intersect(hipStream_t s, const RenderArgs &a, int par, int depth, bool count)
+void launch_intersect(hipStream_t s, const RenderArgs &a, int par, int depth, bool count, int stages)
 {
 	// (the same arithmetic as pulling_grid / per_kind in the kernels)
 	const unsigned blocks = kShards * ((a.grid_cap + kBlock * a.rays_per_lane - 1) / (kBlock * a.rays_per_lane)) + kShards * (a.grid_cap / kBlock);
 	const unsigned leafwise_blocks = 2 * kShards * (a.grid_cap / kBlock);
 	const unsigned camera_blocks = kShards * (a.grid_cap / kBlock);
-	if (a.camera_cells) {
+	if (a.camera_cells && (stages & kStageCamera)) {
 		// Camera rays from their cells' lists first (their bounce rays may join this step's); the traversal kernel
 		// that follows is launched without its workgroups for camera rays (they come last in every grid).
 		if (count)
@@ -1521,7 +1523,9 @@ void launch_intersect(hipStream_t s, const RenderArgs &a, int par, int depth, bo
 		else
 			hipLaunchKernelGGL(k_camera_cells<false>, dim3(camera_blocks), dim3(kBlock), 0, s, a, par);
 	}
-	if (a.leafwise && count)
+	if (!(stages & kStageWalk))
+		;
+	else if (a.leafwise && count)
 		hipLaunchKernelGGL(k_intersect_leafwise<true>, dim3(a.camera_cells ? camera_blocks : leafwise_blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);
 	else if (a.leafwise)
 		hipLaunchKernelGGL(k_intersect_leafwise<false>, dim3(a.camera_cells ? camera_blocks : leafwise_blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);
@@ -1553,7 +1557,9 @@ void launch_intersect(hipStream_t s, const RenderArgs &a, int par, int depth, bo
 		hipLaunchKernelGGL((k_intersect<false, false>), dim3(blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);
 	// on a tame tree odd rays are rare: one workgroup per sub-queue is plenty
 	const unsigned odd_blocks = a.tree.tame ? kShards : kShards * (a.grid_cap / kBlock);
-	if (count)
+	if (!(stages & kStageOdd))
+		;
+	else if (count)
 		hipLaunchKernelGGL(k_intersect_odd<true>, dim3(odd_blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);
 	else
 		hipLaunchKernelGGL(k_intersect_odd<false>, dim3(odd_blocks), dim3(kBlock), stack_bytes(depth), s, a, par,

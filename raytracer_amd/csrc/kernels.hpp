@@ -34,6 +34,7 @@ struct Counters {
 	unsigned long long retraced;            // closest-hit queries that the certified walk left to the exact traversal
 	unsigned long long walked;              // closest-hit queries handed to the certified walk (retraced ones included)
 	unsigned long long listed;              // camera rays answered from their cell's triangle list (retraced ones included)
+	unsigned long long cell_tests;          // RTA_RENDER_COUNT_WORK only: triangle tests of those (also counted in `tri`)
 };
 
 struct TreeRef {
@@ -173,7 +174,11 @@ size_t cell_sort_temp_bytes(size_t entries);
 hipError_t launch_cell_fill(hipStream_t s, const TreeRef &tree, uint32_t n_wide, uint32_t n_prims, const Projection &pr, int map_w,
                             int map_h, uint32_t *counts, const uint32_t *starts, size_t entries, uint32_t *list_unsorted,
                             unsigned long long *keys_unsorted, uint32_t *list, unsigned long long *keys, void *temp, size_t temp_bytes);
-void launch_intersect(hipStream_t s, const RenderArgs &a, int par, int depth, bool count);
+// The closest-hit part of a wavefront step, three launches in this order: camera rays from their cells' lists
+// (k_camera_cells, where the render has such lists), the traversal proper (k_intersect / k_intersect_leafwise), the rays
+// left over for the exact traversal (k_intersect_odd).  `stages`: which of them to issue.
+constexpr int kStageCamera = 1, kStageWalk = 2, kStageOdd = 4, kStageAll = 7;
+void launch_intersect(hipStream_t s, const RenderArgs &a, int par, int depth, bool count, int stages = kStageAll);
 void launch_shadow(hipStream_t s, const RenderArgs &a, int depth, bool count);
 void launch_sum_blocks(hipStream_t s, const float4 *partial, const int32_t *pixels, uint32_t n_pad, uint32_t n_blocks,
                        float *frame, bool resume);

@@ -21,8 +21,8 @@ import os
 import shutil
 import sys
 
-KERNELS = ("k_intersect_odd", "k_intersect_leafwise", "k_intersect", "k_advance", "k_shadow", "k_sum_blocks", "k_resolve",
-           "k_fill_far", "k_part_weights", "k_cover_leaves", "k_sky_map", "k_init_slots")
+KERNELS = ("k_intersect_odd", "k_intersect_leafwise", "k_intersect", "k_camera_cells", "k_advance", "k_shadow", "k_sum_blocks",
+           "k_resolve", "k_fill_far", "k_part_weights", "k_cover_leaves", "k_sky_map", "k_cell_lists", "k_init_slots")
 XCDS, SIMDS, CUS, CLOCK = 8, 1024, 256, 2.4e9
 
 
@@ -147,7 +147,7 @@ def main():
         out["kernels"][k] = e
     with open(os.path.join(dst, "pmc_roofline.json"), "w") as f:
         json.dump(out, f, indent=1)
-    print(json.dumps({k: out["kernels"].get(k) for k in ("k_intersect", "k_advance")}, indent=1))
+    print(json.dumps({k: out["kernels"].get(k) for k in ("k_intersect", "k_camera_cells", "k_advance")}, indent=1))
 
 
 if __name__ == "__main__":

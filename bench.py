@@ -547,8 +547,9 @@ def roofline_render(w, excl, count, m):
         if pj.get("workload") == w["label"]:
             k = pj["kernels"].get(w.get("kernel", "k_intersect"), {})
             if "hbm_bytes_per_launch" in k:
-                # per launch of the same workload in the profiled run
-                out["traffic"] = k["hbm_bytes_per_launch"]
+                # the kernel's HBM bytes per render of the profiled run (same workload; its launches may be cut
+                # differently: four slot groups there, one here), over this run's launches
+                out["traffic"] = k["hbm_bytes_per_launch"] * k["launches"] / max(pj.get("renders_per_profiled_run", 1), 1) / launches
                 out["traffic_over_algorithmic"] = out["traffic"] / per_launch if per_launch else None
                 out["hbm_frac_from_counters"] = out["traffic"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if avg_ms > 0 else None
             out["counters"] = {"source": "profiles/pmc_roofline.json (%s)" % pj.get("tag"), "kernels": pj["kernels"]}

@@ -929,6 +929,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		const size_t max_cap = (size_t)((max_group_blocks + kShards - 1) / kShards) * 256;
 		HIP_TRY(ctx, ctx->q_ray.reserve((size_t)2 * kRayKinds * kShards * max_cap * groups * 4));
 		HIP_TRY(ctx, ctx->q_bounce.reserve((size_t)2 * kShards * max_cap * 2 * groups * 16));
+		HIP_TRY(ctx, ctx->q_camera.reserve((size_t)2 * kShards * max_cap * groups * 16));
 		if (ctx->n_lights > 0)
 			HIP_TRY(ctx, ctx->shadow.reserve((size_t)groups * kShards * max_cap * 48));      // kShards sub-queues per group
 	}
@@ -1119,9 +1120,9 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	}
 	if (with_cells) {
 		base.camera_cells = 1;
+		base.hint = nullptr;          // (hints are the walk's)
 		static const char *first_hit = getenv("RTA_SHADE_FIRST_HIT");      // measurement
 		base.shade_first_hit = ctx->n_lights == 0 && (first_hit ? atoi(first_hit) != 0 : true) ? 1u : 0u;
-		base.hint = ctx->hint.as<int32_t>();
 		base.cell_start = ctx->cell_starts.as<const uint32_t>();
 		base.cell_list = ctx->cell_list.as<const uint32_t>();
 		base.cell_keys = ctx->cell_keys.as<const unsigned long long>();
@@ -1221,6 +1222,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		a.shadow = ctx->shadow.as<float4>() ? ctx->shadow.as<float4>() + 3 * (size_t)g * kShards * shard_cap : nullptr;
 		a.q_ray = ctx->q_ray.as<uint32_t>() + (size_t)g * group_queue;
 		a.q_bounce = ctx->q_bounce.as<float4>() + (size_t)g * group_bounce;
+		a.q_camera = ctx->q_camera.as<float4>() + (size_t)g * (group_bounce / 2);
 		a.shard_cap = shard_cap;
 		a.grid_cap = shard_cap;
 		a.cnt = ctx->counters.as<Counters>() + g;

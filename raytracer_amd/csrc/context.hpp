@@ -75,7 +75,7 @@ struct rta_context {
 	uint32_t wide_n_nodes = 0;
 
 	// wavefront workspace
-	rta::DeviceBuffer ray0, ray1, hit, thr, col, rng, acc, meta, hint, q_ray, q_bounce, shadow, partial, pixels, frame, bgr, counters;
+	rta::DeviceBuffer ray0, ray1, hit, thr, col, rng, acc, meta, hint, q_ray, q_bounce, q_camera, shadow, partial, pixels, frame, bgr, counters;
 	rta::DeviceBuffer part_weights, part_order;
 	rta::DeviceBuffer cover, sky_map;         // see k_sky_map
 	rta::DeviceBuffer cell_counts, cell_starts, cell_list, cell_keys, cell_unsorted, cell_temp;     // per-cell triangle lists of the prepared view (cells.hip)

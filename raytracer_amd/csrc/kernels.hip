@@ -116,7 +116,7 @@ RTA_DEV Ray slot_ray(const RenderArgs &a, uint32_t slot)
 // both) join their queues with ONE atomic on the shard's 64-bit pair of counters: an atomic that
 // returns a value is a round trip to the memory side that the wave sits out.  Must be reached by
 // every lane of the wave.
-RTA_DEV void ray_queues_push(const RenderArgs &a, int par, bool camera, bool bounce, uint32_t slot, const Ray &ray)
+RTA_DEV void ray_queues_push(const RenderArgs &a, int par, bool camera, bool bounce, uint32_t slot, const Ray &ray, int32_t cell)
 {
 	const bool tame = a.tree.tame != 0 && ray_is_tame(ray);
 	const uint32_t shard = blockIdx.x % kShards;
@@ -132,6 +132,10 @@ RTA_DEV void ray_queues_push(const RenderArgs &a, int par, bool camera, bool bou
 		if (camera && tame) {
 			const uint32_t at = base_c + __builtin_amdgcn_mbcnt_hi((uint32_t)(cam >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cam, 0u));
 			a.q_ray[(size_t)qc * a.shard_cap + at] = slot;
+			// with cell lists the entry carries the ray (a pinhole's: its direction) and its cell, so that
+			// k_camera_cells reads its rays from consecutive lines instead of gathering them from the slots
+			if (a.camera_cells)
+				a.q_camera[((size_t)par * kShards + shard) * a.shard_cap + at] = make_float4(ray.d.x, ray.d.y, ray.d.z, __int_as_float(cell));
 		}
 		if (bounce && tame) {
 			const uint32_t at = base_b + __builtin_amdgcn_mbcnt_hi((uint32_t)(bnc >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bnc, 0u));
@@ -615,8 +619,6 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 	if (ray_later && need_ray)
 		next_ray = camera_ray(a, sky_pu, sky_pv, held, cell);
 	if (need_ray) {
-		if (a.camera_cells)
-			a.hint[slot] = cell;
 		a.acc[slot] = A;
 		a.rng[slot] = rng;
 		if (meta_changed)
@@ -635,7 +637,7 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 
 	// camera rays are coherent (a wave's rays cross one tile), bounce rays are not:
 	// they are queued apart so that a traversal wave holds rays of one kind
-	ray_queues_push(a, par, need_ray, alive, slot, next_ray);
+	ray_queues_push(a, par, need_ray, alive, slot, next_ray, cell);
 	if (a.n_lights > 0) {
 		const uint32_t shard = blockIdx.x % kShards;
 		const uint32_t at_sh = queue_push(shadow.wanted, &a.cnt->n_shadow[shard]);
@@ -801,8 +803,9 @@ __global__ __launch_bounds__(kBlock) void k_camera_cells(const RenderArgs a, con
 	Ray ray = {mk(0, 0, 0), mk(1, 1, 1)};
 	if (active) {
 		slot = a.q_ray[(size_t)q * a.shard_cap + i];
-		ray = slot_ray(a, slot);
-		cell = a.hint[slot];
+		const float4 e = a.q_camera[((size_t)par * kShards + shard) * a.shard_cap + i];
+		ray = Ray{mk(a.cam.origin[0], a.cam.origin[1], a.cam.origin[2]), mk(e.x, e.y, e.z)};
+		cell = __float_as_int(e.w);
 	}
 	WorkCount wc = {0, 0, 0};
 	HitRec h;

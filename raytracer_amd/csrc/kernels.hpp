@@ -99,10 +99,12 @@ struct RenderArgs {
 	uint32_t camera_walk;          // camera rays take the certified walk too (the camera lies within the wide tree's reach)
 	int32_t *hint;                 //   and start with the triangle the slot's last camera ray hit, [slot]; -1: none
 	uint32_t wide_cap;             // > 0: bounce rays take the certified walk over the wide tree, with this many LDS entries per lane
-	// Camera rays answered from per-cell triangle lists (cells.hip) instead: `hint` then holds the cell of the
-	// slot's camera ray (its place on the image plane, -1: none), cell_start[cell] .. cell_start[cell + 1] are
-	// the cell's entries of cell_list (triangle numbers)
+	// Camera rays answered from per-cell triangle lists (cells.hip) instead: the camera queues' entries then
+	// come with (direction, cell) in q_camera, [step parity][shard][shard_cap] - the cell is the ray's place on
+	// the image plane, -1: none -, and cell_start[cell] .. cell_start[cell + 1] are the cell's entries of
+	// cell_list (triangle numbers)
 	uint32_t camera_cells;
+	float4 *q_camera;
 	uint32_t shade_first_hit;      //   and those that hit are shaded where they are answered (k_camera_cells; scenes without lights)
 	const uint32_t *cell_start, *cell_list;
 	const unsigned long long *cell_keys;      // per entry: cell << 32 | bits of the nearest t the entry's triangle can be hit at

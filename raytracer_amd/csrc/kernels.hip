@@ -116,9 +116,13 @@ RTA_DEV Ray slot_ray(const RenderArgs &a, uint32_t slot)
 // both) join their queues with ONE atomic on the shard's 64-bit pair of counters: an atomic that
 // returns a value is a round trip to the memory side that the wave sits out.  Must be reached by
 // every lane of the wave.
-RTA_DEV void ray_queues_push(const RenderArgs &a, int par, bool camera, bool bounce, uint32_t slot, const Ray &ray, int32_t cell)
+// With cell lists (RenderArgs::camera_cells) a camera sample is queued before its ray exists: as its two random
+// numbers and its pixel (`sample`), from which k_camera_cells makes the ray - with all its lanes, where the
+// few lanes of a k_advance wave that have a new sample would run the ray's logarithm, sine and cosine alone.
+RTA_DEV void ray_queues_push(const RenderArgs &a, int par, bool camera, bool bounce, uint32_t slot, const Ray &ray, const float4 sample)
 {
-	const bool tame = a.tree.tame != 0 && ray_is_tame(ray);
+	// (a camera sample's ray is looked at where it is made)
+	const bool tame = (camera && a.camera_cells) || (a.tree.tame != 0 && ray_is_tame(ray));
 	const uint32_t shard = blockIdx.x % kShards;
 	const unsigned long long cam = __ballot(camera && tame), bnc = __ballot(bounce && tame);
 	if (cam | bnc) {
@@ -132,10 +136,8 @@ RTA_DEV void ray_queues_push(const RenderArgs &a, int par, bool camera, bool bou
 		if (camera && tame) {
 			const uint32_t at = base_c + __builtin_amdgcn_mbcnt_hi((uint32_t)(cam >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cam, 0u));
 			a.q_ray[(size_t)qc * a.shard_cap + at] = slot;
-			// with cell lists the entry carries the ray (a pinhole's: its direction) and its cell, so that
-			// k_camera_cells reads its rays from consecutive lines instead of gathering them from the slots
 			if (a.camera_cells)
-				a.q_camera[((size_t)par * kShards + shard) * a.shard_cap + at] = make_float4(ray.d.x, ray.d.y, ray.d.z, __int_as_float(cell));
+				a.q_camera[((size_t)par * kShards + shard) * a.shard_cap + at] = sample;
 		}
 		if (bounce && tame) {
 			const uint32_t at = base_b + __builtin_amdgcn_mbcnt_hi((uint32_t)(bnc >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bnc, 0u));
@@ -616,7 +618,7 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 		}
 	}
 
-	if (ray_later && need_ray)
+	if (ray_later && need_ray && !a.camera_cells)
 		next_ray = camera_ray(a, sky_pu, sky_pv, held, cell);
 	if (need_ray) {
 		a.acc[slot] = A;
@@ -637,7 +639,7 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 
 	// camera rays are coherent (a wave's rays cross one tile), bounce rays are not:
 	// they are queued apart so that a traversal wave holds rays of one kind
-	ray_queues_push(a, par, need_ray, alive, slot, next_ray, cell);
+	ray_queues_push(a, par, need_ray, alive, slot, next_ray, make_float4(held.u1, held.u2, __uint_as_float(sky_pixel), 0.f));
 	if (a.n_lights > 0) {
 		const uint32_t shard = blockIdx.x % kShards;
 		const uint32_t at_sh = queue_push(shadow.wanted, &a.cnt->n_shadow[shard]);
@@ -803,10 +805,17 @@ __global__ __launch_bounds__(kBlock) void k_camera_cells(const RenderArgs a, con
 	Ray ray = {mk(0, 0, 0), mk(1, 1, 1)};
 	if (active) {
 		slot = a.q_ray[(size_t)q * a.shard_cap + i];
+		// the sample as k_advance drew it: the pixel filter's two random numbers and the pixel (src/main.cpp:674-687)
 		const float4 e = a.q_camera[((size_t)par * kShards + shard) * a.shard_cap + i];
-		ray = Ray{mk(a.cam.origin[0], a.cam.origin[1], a.cam.origin[2]), mk(e.x, e.y, e.z)};
-		cell = __float_as_int(e.w);
+		const uint32_t pixel = __float_as_uint(e.z);
+		ray = camera_ray(a, pixel % a.width, pixel / a.width, CameraDraws{0.f, 0.f, e.x, e.y}, cell);
 	}
+	// the slot does not know its ray yet: whoever looks at the ray after this kernel finds it there
+	bool ray_wanted = false;
+	// (a ray that needs the division-based box test goes the way of those the lists leave in doubt)
+	const bool odd = active && !(a.tree.tame != 0 && ray_is_tame(ray));
+	if (odd)
+		cell = -1;
 	WorkCount wc = {0, 0, 0};
 	HitRec h;
 	bool doubt;
@@ -836,10 +845,13 @@ __global__ __launch_bounds__(kBlock) void k_camera_cells(const RenderArgs a, con
 			}
 		} else {
 			a.hit[slot] = H;
+			ray_wanted = h.prim >= 0;      // k_advance shades it
 		}
 	}
 	// a ray whose answer is not proven goes to the exact traversal (k_intersect_odd)
 	const bool again = active && doubt;
+	if (again || ray_wanted)
+		a.ray1[slot] = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(0u));
 	if (__ballot(again)) {
 		const uint32_t qd = ray_queue_index(par, kDoubtRays, shard);
 		const uint32_t at = queue_push(again, &a.cnt->n_ray[qd]);

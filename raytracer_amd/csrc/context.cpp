@@ -1122,7 +1122,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		base.camera_cells = 1;
 		base.hint = nullptr;          // (hints are the walk's)
 		static const char *first_hit = getenv("RTA_SHADE_FIRST_HIT");      // measurement
-		base.shade_first_hit = ctx->n_lights == 0 && (first_hit ? atoi(first_hit) != 0 : true) ? 1u : 0u;
+		base.shade_first_hit = (first_hit ? atoi(first_hit) != 0 : true) ? 1u : 0u;
 		base.cell_start = ctx->cell_starts.as<const uint32_t>();
 		base.cell_list = ctx->cell_list.as<const uint32_t>();
 		base.cell_keys = ctx->cell_keys.as<const unsigned long long>();
@@ -1307,18 +1307,20 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 					// advance queues the step's rays; shadow comes before intersect, whose
 					// first workgroup empties the occlusion queue for the next step
 					HIP_TRY_R(timed(gs[g], 2, [&] { launch_advance(gs[g], a, par); }));
+					// camera rays from their cells' lists: what their hits queue (a bounce ray, an occlusion query)
+					// joins this step's queues
+					if (a.camera_cells)
+						HIP_TRY_R(timed(gs[g], 3, [&] { launch_intersect(gs[g], a, par, ctx->stack_depth, count_work, kStageCamera); }));
 					if (lights)
 						HIP_TRY_R(timed(gs[g], 1, [&] {
 							launch_shadow(gs[g], a, ctx->stack_depth, count_work);
 						}));
 					if (time_kernels) {
 						// (the three launches of the closest-hit part, each with its own pair of events)
-						if (a.camera_cells)
-							HIP_TRY_R(timed(gs[g], 3, [&] { launch_intersect(gs[g], a, par, ctx->stack_depth, count_work, kStageCamera); }));
 						HIP_TRY_R(timed(gs[g], 0, [&] { launch_intersect(gs[g], a, par, ctx->stack_depth, count_work, kStageWalk); }));
 						HIP_TRY_R(timed(gs[g], 4, [&] { launch_intersect(gs[g], a, par, ctx->stack_depth, count_work, kStageOdd); }));
 					} else
-						launch_intersect(gs[g], a, par, ctx->stack_depth, count_work);
+						launch_intersect(gs[g], a, par, ctx->stack_depth, count_work, kStageWalk | kStageOdd);
 				}
 				steps++;
 			}

@@ -240,6 +240,8 @@ struct ShadowQuery {
 	float dist;
 };
 
+// LIGHTS = false: for scenes known to have no light (no emission, no light sampling: less code and fewer registers)
+template <bool LIGHTS = true>
 RTA_DEV bool shade_hit(const RenderArgs &a, const uint32_t slot, const uint32_t bounce, const Ray &ray, const float prev_pdf,
                        const float4 H, uint32_t &rng, V3 &thr, V3 &color, Ray &next_ray, float &next_pdf, ShadowQuery &shadow)
 {
@@ -277,7 +279,7 @@ RTA_DEV bool shade_hit(const RenderArgs &a, const uint32_t slot, const uint32_t 
 	const V3 v = to_local(fr, -ray.d);
 
 	// emitted light, MIS-weighted after the first bounce (src/main.cpp:531-543)
-	if (front && light_id >= 0) {
+	if (LIGHTS && front && light_id >= 0) {
 		const float4 *L = a.lights + 7 * (size_t)light_id;
 		const V3 le = xyz(L[0]);
 		if (bounce == 0 || a.n_lights == 0) {
@@ -292,7 +294,7 @@ RTA_DEV bool shade_hit(const RenderArgs &a, const uint32_t slot, const uint32_t 
 
 	// next-event estimation on one uniformly chosen triangle light
 	// (src/main.cpp:545-571); the visibility test is deferred to k_shadow
-	if (a.n_lights > 0) {
+	if (LIGHTS && a.n_lights > 0) {
 		const uint32_t li = rng_next(rng) % (uint32_t)a.n_lights;
 		const float4 *L = a.lights + 7 * (size_t)li;
 		// src/main.cpp:115-131
@@ -784,13 +786,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 // (traverse_cells.hpp, cells.hip), one ray per lane; runs before the step's k_intersect.  Grid: one workgroup
 // per kBlock entries of the camera sub-queues, shards innermost.
 //
-// With RenderArgs::shade_first_hit (scenes without lights) a ray that hits is shaded here as well - bounce 0
-// of RayTrace (src/main.cpp:507-589) with throughput 1 and radiance 0, from the slot's random stream where
-// k_advance left it - and its bounce ray joins the step's bounce queue, which k_intersect traces next: a
-// camera sample that hits takes one pass of k_advance less, and the lanes that shade are compact here.  A
-// slot's bounce ray goes to the sub-queue its camera ray came from (the slot's own, see ray_queues_push), so
-// no sub-queue receives more than its slots.
-template <bool COUNT>
+// With RenderArgs::shade_first_hit a ray that hits is shaded here as well - bounce 0 of RayTrace
+// (src/main.cpp:507-589) with throughput 1 and radiance 0, from the slot's random stream where k_advance left
+// it - and its bounce ray joins the step's bounce queue, which the traversal kernel traces next, its occlusion
+// query the step's occlusion queue, which k_shadow answers next: a camera sample that hits takes one pass of
+// k_advance less, and the lanes that shade are compact here.  A slot's bounce ray and occlusion query go to the
+// sub-queues its camera ray came from (the slot's own, see ray_queues_push), so no sub-queue receives more than
+// its slots.
+template <bool COUNT, bool LIGHTS>
 __global__ __launch_bounds__(kBlock) void k_camera_cells(const RenderArgs a, const int par)
 {
 	const uint32_t shard = blockIdx.x % kShards, part = blockIdx.x / kShards;
@@ -822,16 +825,17 @@ __global__ __launch_bounds__(kBlock) void k_camera_cells(const RenderArgs a, con
 	closest_from_cell<COUNT>(a.tree, active, ray, cell, a.cell_start, a.cell_list, a.cell_keys, h, doubt, wc);
 	bool onward = false;
 	Ray next_ray = {mk(0, 0, 0), mk(1, 1, 1)};
+	ShadowQuery shadow = {false, mk(0, 0, 0), mk(0, 0, 0), mk(0, 0, 0), 0.f};
 	if (active && !doubt) {
 		const float4 H = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
 		if (a.shade_first_hit && h.prim >= 0) {
 			uint32_t rng = a.rng[slot];
 			V3 thr = mk(1, 1, 1), color = mk(0, 0, 0);
 			float next_pdf = 0.f;
-			ShadowQuery none = {false, mk(0, 0, 0), mk(0, 0, 0), mk(0, 0, 0), 0.f};      // (no lights: never wanted)
-			onward = shade_hit(a, slot, 0u, ray, 1.f, H, rng, thr, color, next_ray, next_pdf, none);      // (a pinhole's rays: pdf 1)
+			onward = shade_hit<LIGHTS>(a, slot, 0u, ray, 1.f, H, rng, thr, color, next_ray, next_pdf, shadow);      // (a pinhole's rays: pdf 1)
 			a.rng[slot] = rng;
-			const bool gathered = (__float_as_uint(color.x) | __float_as_uint(color.y) | __float_as_uint(color.z)) != 0;
+			// (as in k_advance: with lights nearly every path gathers at once)
+			const bool gathered = LIGHTS || (__float_as_uint(color.x) | __float_as_uint(color.y) | __float_as_uint(color.z)) != 0;
 			if (onward) {
 				a.ray0[slot] = make_float4(next_ray.o.x, next_ray.o.y, next_ray.o.z, next_pdf);
 				a.ray1[slot] = make_float4(next_ray.d.x, next_ray.d.y, next_ray.d.z, __uint_as_float(1u | (gathered ? kHasColour : 0u)));
@@ -857,6 +861,16 @@ __global__ __launch_bounds__(kBlock) void k_camera_cells(const RenderArgs a, con
 		const uint32_t at = queue_push(again, &a.cnt->n_ray[qd]);
 		if (again)
 			a.q_ray[(size_t)qd * a.shard_cap + at] = slot;
+	}
+	// the occlusion query of the light sampled at the hit joins the step's queue: k_shadow runs after this kernel
+	if (LIGHTS && __ballot(shadow.wanted)) {
+		const uint32_t at_sh = queue_push(shadow.wanted, &a.cnt->n_shadow[shard]);
+		if (shadow.wanted) {
+			float4 *e = a.shadow + 3 * ((size_t)shard * a.shard_cap + at_sh);
+			e[0] = f4(shadow.o, shadow.dist);
+			e[1] = f4u(shadow.d, slot);
+			e[2] = f4(shadow.c, 0.f);
+		}
 	}
 	if (COUNT && wc.tri)
 		atomicAdd(&a.cnt->cell_tests, (unsigned long long)wc.tri);
@@ -1533,10 +1547,14 @@ void launch_intersect(hipStream_t s, const RenderArgs &a, int par, int depth, bo
 	if (a.camera_cells && (stages & kStageCamera)) {
 		// Camera rays from their cells' lists first (their bounce rays may join this step's); the traversal kernel
 		// that follows is launched without its workgroups for camera rays (they come last in every grid).
-		if (count)
-			hipLaunchKernelGGL(k_camera_cells<true>, dim3(camera_blocks), dim3(kBlock), 0, s, a, par);
+		if (count && a.n_lights > 0)
+			hipLaunchKernelGGL((k_camera_cells<true, true>), dim3(camera_blocks), dim3(kBlock), 0, s, a, par);
+		else if (count)
+			hipLaunchKernelGGL((k_camera_cells<true, false>), dim3(camera_blocks), dim3(kBlock), 0, s, a, par);
+		else if (a.n_lights > 0)
+			hipLaunchKernelGGL((k_camera_cells<false, true>), dim3(camera_blocks), dim3(kBlock), 0, s, a, par);
 		else
-			hipLaunchKernelGGL(k_camera_cells<false>, dim3(camera_blocks), dim3(kBlock), 0, s, a, par);
+			hipLaunchKernelGGL((k_camera_cells<false, false>), dim3(camera_blocks), dim3(kBlock), 0, s, a, par);
 	}
 	if (!(stages & kStageWalk))
 		;

@@ -14,6 +14,6 @@ scene.set_render(1920, 1080, int(os.environ.get("SPP", "64")))
 for flags in (rta.RENDER_COUNT_WORK, 0):
     _, _, st = ctx.render_scene(scene, seed=69420, samples_per_stream=8, flags=flags, want_accum=False, want_bgr=False)
     traced = st["rays"] - st["early_rays"]
-    print({k: st[k] for k in ("samples", "rays", "early_rays", "walked_rays", "listed_rays", "retraced_rays", "inner_visits", "tri_tests", "sph_tests")},
-          f"traced {traced}, per traced ray: {st['inner_visits'] / traced:.2f} visits, {st['tri_tests'] / traced:.2f} tests, {st['sph_tests'] / traced:.2f} census; {st['gpu_ms']:.1f} ms",
+    print({k: st[k] for k in ("samples", "rays", "early_rays", "walked_rays", "listed_rays", "retraced_rays", "inner_visits", "tri_tests", "sph_tests", "cell_tests")},
+          f"traced {traced}, per traced ray: {st['inner_visits'] / traced:.2f} visits, {st['tri_tests'] / traced:.2f} tests, {st['sph_tests'] / traced:.2f} census; {st['cell_tests'] / max(st['listed_rays'], 1):.2f} list tests per listed ray; {st['gpu_ms']:.1f} ms",
           flush=True)

@@ -1049,6 +1049,10 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		base.walk_waiting = lanes(waiting, 16u);
 	}
 	base.rays_per_lane = 8;       // measured on dragon.txt: 4 and 12 lose 1-2 %
+	{
+		static const char *spread = getenv("RTA_SPREAD");      // measurement
+		base.spread_blocks = spread ? (uint32_t)std::min(std::max(atoi(spread), 1), 1024) : 8u;
+	}
 	base.refill_at = 24;          // likewise 16 (8 loses 3 %)
 
 	const bool time_kernels = (p->flags & RTA_RENDER_TIME_KERNELS) != 0;

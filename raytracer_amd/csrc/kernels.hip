@@ -715,7 +715,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 		const uint32_t total = a.cnt->n_ray[q];
 		// a short list is spread over up to 8 workgroups rather than worked through by
 		// one: towards the end of a render the steps are as long as their longest wave
-		const uint32_t spread = (total + 8 * kBlock - 1) / (8 * kBlock);
+		const uint32_t spread = (total + a.spread_blocks * kBlock - 1) / (a.spread_blocks * kBlock);
 		const uint32_t rays_per_lane = spread < a.rays_per_lane ? (spread ? spread : 1u) : a.rays_per_lane;
 		if (part < pulling_blocks(total, rays_per_lane)) {
 			const float4 *queue = a.q_bounce + 2 * ((size_t)par * kShards + shard) * a.shard_cap;

@@ -93,6 +93,7 @@ struct RenderArgs {
 	uint32_t grid_cap;             // entries per sub-queue that a traversal launch's grid covers: a multiple of the workgroup
 	                               // size, <= shard_cap, and at least the number of slots that can still queue a ray
 	uint32_t rays_per_lane, refill_at;     // bounce-ray traversal: see traverse_pulling
+	uint32_t spread_blocks;        //   a sub-queue's rays are spread over at least so many workgroups (fewer rays per lane)
 	uint32_t leafwise;             // the tree has long leaves: traverse_leafwise, one ray per lane (rays_per_lane = 1)
 	uint32_t walk_refill_at, walk_quorum, walk_waiting;      // traverse_wide_pulling's thresholds for the render's rays
 	uint32_t sort_lanes;           // k_advance: the lanes of a workgroup trade slots so that its waves hold one kind of work each

@@ -28,7 +28,11 @@ int rta_debug_arith(rta_context *ctx, int op, const float *x, const float *y, fl
 int rta_debug_trace_variant(rta_context *ctx, int variant, const float *rays, int64_t n, rta_hit *hits, int mem);
 
 /* Test hook: the device layouts of the uploaded scene, copied to the host.  which: 0 pair records, 1 primitive
- * records, 2 shading records, 3 the reference's node records, 4 the wide tree's nodes, 5 the leaf boxes;
+ * records, 2 shading records, 3 the reference's node records, 4 the wide tree's nodes, 5 the leaf boxes; 7, 8, 9: the
+ * camera's cell lists of the view that the last render prepared (per cell of the image plane - the frame and three
+ * cells around it, row by row - where its entries start, one more word for their total; the entries' triangle
+ * numbers; the entries' keys: cell << 32 | bits of the least t at which the triangle can be hit through the cell),
+ * empty where that render made none;
  * 6: sixteen 32-bit words of scalars (pair count, root reference, tame, box known, the box's six floats, stack
  * depth, wide tree present, its depth, index mask, reach, span).  *bytes receives the size; out may be NULL to
  * ask for it, else cap must be at least that.  Used to compare the two upload paths (host-built and

@@ -464,7 +464,8 @@ class Context:
 
     def scene_buffer(self, which):
         """A device layout of the uploaded scene as bytes (rta_debug_scene_buffer): 0 pairs, 1 primitives,
-        2 shading records, 3 reference nodes, 4 wide nodes, 5 leaf boxes, 6 scalars."""
+        2 shading records, 3 reference nodes, 4 wide nodes, 5 leaf boxes, 6 scalars; 7, 8, 9: the cell lists of the view the
+        last render prepared (starts, triangle numbers, keys)."""
         n = C.c_size_t(0)
         self._check(probe_lib().rta_debug_scene_buffer(self._h, which, None, 0, C.byref(n)))
         out = np.empty(n.value, np.uint8)

@@ -84,7 +84,25 @@ int rta_debug_scene_buffer(rta_context *ctx, int which, void *out, size_t cap, s
 	case 2: src = ctx->shade_prims.ptr, n = (size_t)ctx->n_prims * 48; break;
 	case 3: src = ctx->ref_nodes.ptr, n = (size_t)ctx->n_nodes * 32; break;
 	case 4: src = ctx->wide_nodes.ptr, n = ctx->have_wide ? (size_t)ctx->wide_n_nodes * 64 : 0; break;
-	case 5: src = ctx->leaf_boxes.ptr, n = ctx->have_wide ? (size_t)ctx->n_prims * 32 : 0; break;
+	case 5: src = ctx->leaf_boxes.ptr, n = ctx->have_leaf_boxes ? (size_t)ctx->n_prims * 32 : 0; break;
+	// the cell lists of the view that the last render prepared (cells.hip)
+	case 7:
+	case 8:
+	case 9: {
+		const rta_context::Prepared &pre = ctx->prepared;
+		if (!pre.valid || !pre.with_cells) {
+			n = 0;
+			break;
+		}
+		const size_t cells = ((size_t)pre.width + 2 * kSkyBorder) * ((size_t)pre.height + 2 * kSkyBorder);
+		if (which == 7)
+			src = ctx->cell_starts.ptr, n = (cells + 1) * 4;
+		else if (which == 8)
+			src = ctx->cell_list.ptr, n = (size_t)pre.cell_entries * 4;
+		else
+			src = ctx->cell_keys.ptr, n = (size_t)pre.cell_entries * 8;
+		break;
+	}
 	case 6: {
 		scalars[0] = ctx->n_pairs, scalars[1] = ctx->root_ref, scalars[2] = ctx->tame, scalars[3] = ctx->box_known;
 		memcpy(scalars + 4, ctx->box, 24);

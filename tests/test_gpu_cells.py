@@ -119,3 +119,69 @@ def test_triangles_larger_than_the_frame(gpu):
     coarse = _grid(3, lambda x, y: 0.2 * x * y + 0.1 * x)
     st = _render_both(gpu, _mesh_text(coarse, (0.3, -0.2, 1.4), (0.1, 0.05, 0), (0.2, 1, 0), 9, 80, 60, 6), seed=4, sps=3)
     assert st["early_rays"] < st["samples"]
+
+
+def _check_lists(gpu, text, w, h, n=2_000_000, seed=7):
+    import torch
+    psc = rta.Scene.parse(text).build_bvh()
+    gpu.upload(psc)
+    _, _, st = gpu.render_scene(psc, seed=1, samples_per_stream=1)
+    assert st["listed_rays"] > 0
+    border = 3
+    starts = gpu.scene_buffer(7).view(np.uint32)
+    prims = gpu.scene_buffer(8).view(np.uint32)
+    keys = gpu.scene_buffer(9).view(np.uint64)
+    assert starts.size == (w + 2 * border) * (h + 2 * border) + 1 and starts[-1] == prims.size == keys.size > 0
+    cam = psc.camera()
+    o, ul, du, dv = (np.array(v[:], np.float32) for v in (cam.origin, cam.upper_left, cam.du, cam.dv))
+    rng = np.random.default_rng(seed)
+    fx = rng.uniform(-2.9, w + 2.9, n).astype(np.float32)
+    fy = rng.uniform(-2.9, h + 2.9, n).astype(np.float32)
+    target = (ul[None, :] + du[None, :] * fx[:, None]) + dv[None, :] * fy[:, None]
+    d = target - o[None, :]
+    d = (d / np.linalg.norm(d.astype(np.float64), axis=1, keepdims=True)).astype(np.float32)
+    rr = np.concatenate([np.broadcast_to(o, (n, 3)), d], axis=1).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    rt = torch.from_numpy(np.ascontiguousarray(rr)).to(dev)
+    ht = torch.zeros((n, 4), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()      # the library works on its own streams
+    gpu.trace_variant_device(10, rt.data_ptr(), n, ht.data_ptr())
+    got = ht.cpu().numpy()
+    hit_prim, hit_t = got[:, 0].view(np.int32), got[:, 1]
+    cell = (np.floor(fy).astype(np.int64) + border) * (w + 2 * border) + np.floor(fx).astype(np.int64) + border
+    # (spheres are in no list: every camera ray tests them)
+    is_triangle = psc.arrays()["prim_type"] == 0
+    hits = np.nonzero((hit_prim >= 0) & is_triangle[np.maximum(hit_prim, 0)])[0]
+    # every entry as (cell, triangle), sorted: a hit's (cell, triangle) must be one of them
+    entry_cell = (keys >> np.uint64(32)).astype(np.uint64)
+    assert np.array_equal(entry_cell, np.repeat(np.arange(starts.size - 1, dtype=np.uint64), np.diff(starts.astype(np.int64))))
+    entry_bound = (keys & np.uint64(0xffffffff)).astype(np.uint32).view(np.float32)
+    combined = (entry_cell << np.uint64(32)) | prims.astype(np.uint64)
+    order = np.argsort(combined, kind="stable")
+    combined = combined[order]
+    want = (cell[hits].astype(np.uint64) << np.uint64(32)) | hit_prim[hits].astype(np.uint64)
+    at = np.searchsorted(combined, want)
+    found = (at < combined.size) & (combined[np.minimum(at, combined.size - 1)] == want)
+    assert found.all(), int((~found).sum())
+    assert np.all(entry_bound[order][at] <= hit_t[hits])
+    # and the lists are lists, not the whole scene: entries per cell that has any
+    lengths = np.diff(starts.astype(np.int64))
+    return hits.size, float(lengths[lengths > 0].mean())
+
+
+def test_every_hit_lies_in_its_cell_s_list(gpu):
+    """The lists themselves, read back from the device: two million rays aimed anywhere on the image plane (the frame and
+    the filter's reach around it) are traced by the traversal that replays the reference's order; whatever triangle one of
+    them hits must be in the list of the cell it was aimed at, with a key (the least distance at which the triangle can be
+    hit through the cell) no larger than the distance found.  dragon.txt from two sides, cornell_box.txt (walls seen from
+    in front and at a grazing angle: the widening follows each cell's determinant), a bumpy sheet seen edge-on."""
+    base = open(f"{orc.SCENES}/dragon.txt").read()
+    for cam_at, look, fov in (((-1.9, 0.0, 1.0), (0.0, 0.0, 1.0), 40.0), ((0.9, -1.6, 2.4), (0.0, 0.2, 1.0), 65.0)):
+        text = _with_render_block(base, camera=_vec(cam_at), look_at=_vec(look), fov="%r" % fov, width="480", height="270", samples="1")
+        n_hits, mean_len = _check_lists(gpu, text, 480, 270)
+        assert n_hits > 100_000 and mean_len < 16      # (a cell of this small frame spans several triangles)
+    n_hits, mean_len = _check_lists(gpu, orc.scene_variant("cornell_box.txt", 480, 270, 1), 480, 270)
+    assert n_hits > 1_000_000 and mean_len < 8
+    bumpy = _grid(24, lambda x, y: 0.11 * np.sin(5 * x) * np.cos(4 * y))
+    n_hits, mean_len = _check_lists(gpu, _mesh_text(bumpy, (-1.44, 0.1, 0.16), (0.2, 0, 0), (0, 0, 1), 40, 480, 270, 1), 480, 270)
+    assert n_hits > 100_000

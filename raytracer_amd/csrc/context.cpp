@@ -1267,6 +1267,8 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		for (int g = 0; g < kMaxGroups; g++) {
 			memset(&ctx->host_counters[g], 0, sizeof(Counters));
 			ctx->host_counters[g].live = g < groups ? group_slots : 0;
+			// (the first pass of k_advance hands stream i to slot i without asking)
+			ctx->host_counters[g].next_item = g < groups ? group_slots : 0;
 		}
 		HIP_TRY_R(hipMemcpyAsync(ctx->counters.ptr, ctx->host_counters, sizeof(Counters) * kMaxGroups, hipMemcpyHostToDevice, s));
 		HIP_TRY_R(hipStreamSynchronize(s));       // host_counters is reused for read-back below; the groups are idle
@@ -1301,12 +1303,13 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 			ga[g].grid_cap = shard_cap;
 			launch_init_slots(gs[g], ga[g], group_slots);
 		}
-		bool done = false;
+		bool done = false, fresh = true;      // fresh: the slots come straight from k_init_slots
 		int poll = 16;
 		while (!done) {
 			for (int k = 0; k < poll; k++) {
 				for (int g = 0; g < groups; g++) {
-					const RenderArgs &a = ga[g];
+					RenderArgs &a = ga[g];
+					a.first_pass = fresh ? 1u : 0u;
 					const int par = (int)(steps & 1);
 					// advance queues the step's rays; shadow comes before intersect, whose
 					// first workgroup empties the occlusion queue for the next step
@@ -1327,6 +1330,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 						launch_intersect(gs[g], a, par, ctx->stack_depth, count_work, kStageWalk | kStageOdd);
 				}
 				steps++;
+				fresh = false;
 			}
 			HIP_TRY_R(hipGetLastError());
 			for (int g = 0; g < groups; g++)

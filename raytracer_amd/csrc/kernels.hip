@@ -540,10 +540,15 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 		const unsigned long long waiting = __ballot(state == kWaiting);
 		const uint32_t n_wait = (uint32_t)__popcll(waiting);
 		if (n_wait && (n_wait >= a.grab_at || __ballot(state != kWaiting && state != kRetired) == 0)) {
-			uint32_t base = 0;
-			if (lane == 0)
-				base = atomicAdd(&a.cnt->next_item, n_wait);
-			base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+			// (The first pass after k_init_slots finds every lane of every wave waiting.  A quarter of a million
+			// waves taking their places in line at ONE counter cost that pass 2.4 ms, so there the places are
+			// the slots' own numbers and the host starts the counter behind them.)
+			uint32_t base = blockIdx.x * kBlock + (threadIdx.x & ~63u);
+			if (!(a.first_pass && trip == 0)) {      // (lanes that are through with a stream within the pass ask like everyone)
+				if (lane == 0)
+					base = atomicAdd(&a.cnt->next_item, n_wait);
+				base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+			}
 			const uint32_t got = base < a.n_streams ? (a.n_streams - base < n_wait ? a.n_streams - base : n_wait) : 0u;
 			const uint32_t rank =
 			    __builtin_amdgcn_mbcnt_hi((uint32_t)(waiting >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)waiting, 0u));

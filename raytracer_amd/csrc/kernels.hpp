@@ -124,6 +124,7 @@ struct RenderArgs {
 	uint32_t streams_per_part;     // pixels of a part x block runs of the pass
 	uint32_t n_streams;            // in this group's list (Counters::next_item counts them out)
 	uint32_t grab_at;              // waiting lanes that make a wave draw new streams
+	uint32_t first_pass;           // k_advance: the pass right after k_init_slots (slot i draws stream i, Counters::next_item starts at n_slots)
 	// Pinhole cameras looking at a tame tree: per pixel, the value u1 of the pixel
 	// filter's first random number from which on a sample stays clear of every
 	// leaf's box on the image plane (see k_sky_map); null when there is no such map.

@@ -1266,7 +1266,6 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		const uint32_t end_block = (uint32_t)std::min<uint64_t>(range_end, (uint64_t)range_begin + (uint64_t)g1 * blocks_per_group);
 		for (int g = 0; g < kMaxGroups; g++) {
 			memset(&ctx->host_counters[g], 0, sizeof(Counters));
-			ctx->host_counters[g].live = g < groups ? group_slots : 0;
 			// (the first pass of k_advance hands stream i to slot i without asking)
 			ctx->host_counters[g].next_item = g < groups ? group_slots : 0;
 		}
@@ -1340,7 +1339,9 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 			uint64_t live = 0;
 			for (int g = 0; g < groups; g++) {
 				HIP_TRY_R(hipStreamSynchronize(gs[g]));
-				const uint32_t slots = ctx->host_counters[g].live;
+				uint32_t slots = g < groups ? group_slots : 0;      // those that still hold or may get a path
+				for (uint32_t r : ctx->host_counters[g].retired)
+					slots -= r;
 				done = done && slots == 0;
 				live += slots;
 				// A slot that has retired stays retired for the rest of the pass, so the slots still

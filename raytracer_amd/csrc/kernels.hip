@@ -365,6 +365,10 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 {
 	uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
 	const uint32_t lane = threadIdx.x & 63;
+	// How far the group's list of streams had been handed out when this launch began or since (it only ever
+	// grows): a plain load of a wave-uniform address, which goes through the scalar cache - a quarter of a
+	// million waves asking the memory side for ONE word, even just to read it, queue up there.
+	const uint32_t handed_out = a.cnt->next_item;
 	float4 r1 = make_float4(0.f, 0.f, 0.f, __uint_as_float(kRetired)), H = make_float4(0.f, 0.f, 0.f, 0.f);
 	if (a.sort_lanes) {
 		// Which slot a lane works on is free (all state lives in memory, indexed by slot), and what a
@@ -545,9 +549,14 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 			// the slots' own numbers and the host starts the counter behind them.)
 			uint32_t base = blockIdx.x * kBlock + (threadIdx.x & ~63u);
 			if (!(a.first_pass && trip == 0)) {      // (lanes that are through with a stream within the pass ask like everyone)
-				if (lane == 0)
-					base = atomicAdd(&a.cnt->next_item, n_wait);
-				base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+				// (once the list was seen dry no wave needs to ask: the waves that retire together at the end of a
+				// render would otherwise queue at the counter again)
+				base = handed_out;
+				if (handed_out < a.n_streams) {
+					if (lane == 0)
+						base = atomicAdd(&a.cnt->next_item, n_wait);
+					base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+				}
 			}
 			const uint32_t got = base < a.n_streams ? (a.n_streams - base < n_wait ? a.n_streams - base : n_wait) : 0u;
 			const uint32_t rank =
@@ -581,7 +590,7 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 			}
 			// slots that retire are through for the rest of the render
 			if (got < n_wait && lane == 0)
-				atomicSub(&a.cnt->live, n_wait - got);
+				atomicAdd(&a.cnt->retired[(blockIdx.x * (kBlock / 64) + threadIdx.x / 64) % kShards], n_wait - got);
 		}
 		// every lane retired (not so on entry): the wave is through
 		if (__ballot(state != kRetired) == 0)

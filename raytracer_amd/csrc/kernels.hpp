@@ -19,7 +19,7 @@ constexpr uint32_t kRayKinds = 4;     // camera rays, bounce rays, rays needing 
 struct Counters {
 	uint32_t unused0;
 	uint32_t next_item;      // streams of the group's list already handed out
-	uint32_t live;           // slots that still hold or may get a path
+	uint32_t unused1;
 	uint32_t pad;
 	unsigned long long rays, shadow_rays;
 	// closest-hit queue lengths, [step parity][shard][kind]: the camera and the bounce counter of a
@@ -33,6 +33,9 @@ struct Counters {
 	unsigned long long early[kShards];
 	unsigned long long retraced;            // closest-hit queries that the certified walk left to the exact traversal
 	unsigned long long walked;              // closest-hit queries handed to the certified walk (retraced ones included)
+	// slots that are through for the rest of the pass; the sum of the words counts (the waves of a render's end retire
+	// together: on ONE word they would queue up behind one another)
+	uint32_t retired[kShards];
 	unsigned long long listed;              // camera rays answered from their cell's triangle list (retraced ones included)
 	unsigned long long cell_tests;          // RTA_RENDER_COUNT_WORK only: triangle tests of those (also counted in `tri`)
 };

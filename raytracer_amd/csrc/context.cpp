@@ -1147,8 +1147,8 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		launch_part_weights(s, base, ctx->part_weights.as<uint32_t>(), ctx->stack_depth);
 		HIP_TRY_R(hipMemcpyAsync(weight.data(), ctx->part_weights.ptr, (size_t)n_parts * 4, hipMemcpyDeviceToHost, s));
 		HIP_TRY_R(hipStreamSynchronize(s));
-		// parts that only see the sky come off the list: their block sums are written
-		// by k_fill_far, pass by pass
+		// parts that only see the sky come off the list: k_sum_blocks knows their block sums
+		// without anybody writing them
 		std::vector<uint32_t> far;
 		uint32_t start[66] = {0};
 		for (uint32_t w : weight)
@@ -1168,8 +1168,6 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 			for (uint32_t k = 0; k < part_pixels; k++)
 				far_pixels += px[(size_t)(which / lane_blocks) * 64 + (which % lane_blocks) * part_pixels + k] >= 0;
 		HIP_TRY_R(hipMemcpyAsync(ctx->part_order.ptr, order.data(), (size_t)n_listed * 4, hipMemcpyHostToDevice, s));
-		// (the weights are through; their buffer takes the other list)
-		HIP_TRY_R(hipMemcpyAsync(ctx->part_weights.ptr, far.data(), (size_t)n_far * 4, hipMemcpyHostToDevice, s));
 		HIP_TRY_R(hipStreamSynchronize(s));       // `order` and `far` die here
 	}
 	pre.cam = *camera;
@@ -1272,9 +1270,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		HIP_TRY_R(hipMemcpyAsync(ctx->counters.ptr, ctx->host_counters, sizeof(Counters) * kMaxGroups, hipMemcpyHostToDevice, s));
 		HIP_TRY_R(hipStreamSynchronize(s));       // host_counters is reused for read-back below; the groups are idle
 		if (n_far) {
-			RenderArgs fill = base;
-			fill.first_block = first_block;
-			launch_fill_far(s, fill, ctx->part_weights.as<const uint32_t>(), n_far, first_block, end_block);
+			// (k_sum_blocks knows these parts' block sums without anybody writing them)
 			// each of these samples stands for one NearestHit call of the reference, like
 			// the ones k_advance answers
 			const uint64_t pass_samples = std::min<uint64_t>(spp, (uint64_t)end_block * sps) - (uint64_t)first_block * sps;
@@ -1372,7 +1368,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		}
 		// all groups are idle here (synchronised above)
 		if (d_frame && n_owned)
-			launch_sum_blocks(s, base.partial, base.pixels, n_pad, end_block - first_block, d_frame, g0 > 0);
+			launch_sum_blocks(s, base, first_block, end_block - first_block, d_frame, g0 > 0);
 	}
 	if (d_frame && d_bgr && n_owned)
 		launch_resolve(s, d_frame, base.pixels, n_pad, (float)spp, p->exposure, d_bgr);

@@ -147,9 +147,6 @@ void launch_init_slots(hipStream_t s, const RenderArgs &a, uint32_t n_slots);
 void launch_part_weights(hipStream_t s, const RenderArgs &a, uint32_t *weights, int depth);
 // weight of a part none of whose pixels can send a sample to a leaf's box (see k_sky_map)
 constexpr uint32_t kNothingToTrace = 0xffffffffu;
-// block sums of the blocks first_block..end_block-1 for the pixels of the `n_far` parts listed in far_parts
-void launch_fill_far(hipStream_t s, const RenderArgs &a, const uint32_t *far_parts, uint32_t n_far, uint32_t first_block,
-                     uint32_t end_block);
 void launch_advance(hipStream_t s, const RenderArgs &a, int par);
 // Where a pinhole camera sees a point: on the image plane at o + (point - o) * h / ((point - o) . n),
 // pixel coordinates x = (that - ul) . du / du2, y likewise with dv.
@@ -187,8 +184,8 @@ hipError_t launch_cell_fill(hipStream_t s, const TreeRef &tree, uint32_t n_wide,
 constexpr int kStageCamera = 1, kStageWalk = 2, kStageOdd = 4, kStageAll = 7;
 void launch_intersect(hipStream_t s, const RenderArgs &a, int par, int depth, bool count, int stages = kStageAll);
 void launch_shadow(hipStream_t s, const RenderArgs &a, int depth, bool count);
-void launch_sum_blocks(hipStream_t s, const float4 *partial, const int32_t *pixels, uint32_t n_pad, uint32_t n_blocks,
-                       float *frame, bool resume);
+// the pass's blocks (first_block .. first_block + n_blocks - 1, in a.partial) joined to the pixels' sums in `frame`
+void launch_sum_blocks(hipStream_t s, const RenderArgs &a, uint32_t first_block, uint32_t n_blocks, float *frame, bool resume);
 void launch_resolve(hipStream_t s, const float *frame, const int32_t *pixels, uint32_t n, float samples, float exposure,
                     uint8_t *bgr);
 // `order`: null, or the n ray numbers in the order in which they are to be traced (n < 2^32);

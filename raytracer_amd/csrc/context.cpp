@@ -146,6 +146,7 @@ TreeRef tree_of(const rta_context *ctx)
 	t.wide_index_mask = ctx->wide_index_mask;
 	t.n_loose = ctx->have_leaf_boxes ? ctx->n_loose : 0u;
 	t.loose = ctx->loose.as<const uint32_t>();
+	t.flat_prims = 0;
 	t.wide_index_bits = (uint32_t)__builtin_popcount(ctx->wide_index_mask);
 	// with fewer than 11 bits left for the distance, a float's leading bits say too little
 	static const char *relative = getenv("RTA_WIDE_RELATIVE");      // measurement
@@ -1013,6 +1014,17 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	// two large triangles renderable at all (the reference's midpoint split leaves half the mesh in one leaf
 	// with a floor triangle whose box spans the scene: 13 s per 1080p x 256 spp frame replayed, 0.2 s walked).
 	base.leafwise = !base.wide_cap && (uint64_t)ctx->n_prims >= 4 * ((uint64_t)ctx->n_pairs + 1) ? 1u : 0u;
+	// A scene of a few dozen primitives needs no tree: every ray tests them all, in lock-step and mostly without
+	// divisions (traverse_flat.hpp); answers are certified against the leaves' boxes as the walk's are.  (The queues
+	// are those of the leafwise kernels.)
+	{
+		static const char *flat = getenv("RTA_FLAT");      // measurement
+		const bool scan = !base.wide_cap && ctx->n_prims <= (int64_t)kFlatMaxPrims && ctx->have_leaf_boxes && ctx->tame &&
+		                  !(p->flags & RTA_RENDER_EXACT_ONLY) && (flat ? atoi(flat) != 0 : true);
+		base.tree.flat_prims = scan ? (uint32_t)ctx->n_prims : 0u;
+		if (scan)
+			base.leafwise = 1u;
+	}
 	// Camera rays join them when the camera (a pinhole) lies within the wide tree's reach; each starts
 	// with the triangle that the slot's last camera ray hit: the same pixel, most often the same triangle
 	{

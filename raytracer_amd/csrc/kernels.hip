@@ -45,6 +45,7 @@
 #include "traverse.hpp"
 #include "traverse_wide.hpp"
 #include "traverse_cells.hpp"
+#include "traverse_flat.hpp"
 #include "traverse_packet.hpp"
 
 namespace rta {
@@ -936,6 +937,52 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 		count_flush(a.cnt, wc);
 }
 
+// k_intersect for scenes of a few dozen primitives (TreeRef::flat_prims): every ray tests them all
+// (traverse_flat.hpp), one ray per lane; what that leaves in doubt goes to k_intersect_odd.  The grid of
+// k_intersect_leafwise; bounce rays come with their queue entries, camera rays (where no cell lists serve
+// them) from their slots.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_intersect_flat(const RenderArgs a, const int par)
+{
+	if (blockIdx.x == 0)
+		step_housekeeping(a, par);
+	const uint32_t per_kind = kShards * (a.grid_cap / kBlock);
+	const int kind = blockIdx.x < per_kind ? kBounceRays : kCameraRays;
+	const uint32_t rem = blockIdx.x < per_kind ? blockIdx.x : blockIdx.x - per_kind;
+	const uint32_t shard = rem % kShards, part = rem / kShards;
+	const uint32_t q = ray_queue_index(par, kind, shard);
+	const uint32_t total = a.cnt->n_ray[q];
+	if (part * kBlock >= total)
+		return;
+	const uint32_t i = part * kBlock + threadIdx.x;
+	const bool active = i < total;
+	uint32_t slot = 0;
+	Ray ray = {mk(0, 0, 0), mk(1, 1, 1)};
+	if (active && kind == kBounceRays) {
+		const float4 *e = a.q_bounce + 2 * (((size_t)par * kShards + shard) * a.shard_cap + i);
+		const float4 r0 = e[0], r1 = e[1];
+		ray = Ray{mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y)};
+		slot = __float_as_uint(r1.z);
+	} else if (active) {
+		slot = a.q_ray[(size_t)q * a.shard_cap + i];
+		ray = slot_ray(a, slot);
+	}
+	WorkCount wc = {0, 0, 0};
+	HitRec h;
+	bool doubt;
+	scan_flat<false, COUNT>(a.tree, active, ray, FLT_MAX, h, doubt, wc);
+	if (active && !doubt)
+		a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
+	if (__ballot(doubt)) {
+		const uint32_t qd = ray_queue_index(par, kDoubtRays, shard);
+		const uint32_t at = queue_push(doubt, &a.cnt->n_ray[qd]);
+		if (doubt)
+			a.q_ray[(size_t)qd * a.shard_cap + at] = slot;
+	}
+	if (COUNT)
+		count_flush(a.cnt, wc);
+}
+
 // The rays that need the division-based box test, and the rays that the
 // certified walk of the launch before left to the exact traversal.  Any grid that
 // is a multiple of kShards works: the workgroups of a shard stride over its
@@ -994,6 +1041,44 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 			C.z += e2.z;
 			a.col[slot] = C;
 		}
+	}
+	if (COUNT)
+		count_flush(a.cnt, wc);
+}
+
+// k_shadow for scenes of a few dozen primitives (TreeRef::flat_prims): every query tests them all
+// (traverse_flat.hpp).  A query that this cannot answer for certain, or whose ray needs the division-based box
+// test, is traced by the replaying traversal on the spot: such queries are too rare for a queue of their own.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_shadow_flat(const RenderArgs a, const int depth)
+{
+	extern __shared__ uint32_t lds_stack[];
+	const uint32_t shard = blockIdx.x % kShards, part = blockIdx.x / kShards;
+	const uint32_t i = part * kBlock + threadIdx.x;
+	const uint32_t n = a.cnt->n_shadow[shard];
+	if (i == 0 && n)
+		atomicAdd(&a.cnt->shadow_rays, (unsigned long long)n);
+	if (part * kBlock >= n)
+		return;
+	WorkCount wc = {0, 0, 0};
+	const float4 *e = a.shadow + 3 * ((size_t)shard * a.shard_cap + (i < n ? i : 0u));
+	const float4 e0 = e[0], e1 = e[1];
+	const Ray ray = {xyz(e0), xyz(e1)};
+	const bool tame = ray_is_tame(ray);
+	HitRec h;
+	bool doubt;
+	scan_flat<true, COUNT>(a.tree, i < n && tame, ray, e0.w, h, doubt, wc);
+	if (i < n && (doubt || !tame))
+		traverse_leafwise<true, COUNT>(a.tree, ray, e0.w, lds_stack + threadIdx.x, depth, h, wc);
+	if (i < n && h.prim < 0) {
+		// src/main.cpp:569: the light's contribution joins the path radiance
+		const float4 e2 = e[2];
+		const uint32_t slot = __float_as_uint(e1.w);
+		float4 C = a.col[slot];
+		C.x += e2.x;
+		C.y += e2.y;
+		C.z += e2.z;
+		a.col[slot] = C;
 	}
 	if (COUNT)
 		count_flush(a.cnt, wc);
@@ -1558,6 +1643,10 @@ void launch_intersect(hipStream_t s, const RenderArgs &a, int par, int depth, bo
 	}
 	if (!(stages & kStageWalk))
 		;
+	else if (a.tree.flat_prims && count)
+		hipLaunchKernelGGL(k_intersect_flat<true>, dim3(a.camera_cells ? camera_blocks : leafwise_blocks), dim3(kBlock), 0, s, a, par);
+	else if (a.tree.flat_prims)
+		hipLaunchKernelGGL(k_intersect_flat<false>, dim3(a.camera_cells ? camera_blocks : leafwise_blocks), dim3(kBlock), 0, s, a, par);
 	else if (a.leafwise && count)
 		hipLaunchKernelGGL(k_intersect_leafwise<true>, dim3(a.camera_cells ? camera_blocks : leafwise_blocks), dim3(kBlock), stack_bytes(depth), s, a, par, depth);
 	else if (a.leafwise)
@@ -1605,6 +1694,10 @@ void launch_shadow(hipStream_t s, const RenderArgs &a, int depth, bool count)
 	const unsigned blocks = kShards * (a.grid_cap / kBlock);
 	if (a.wide_cap && !count)
 		hipLaunchKernelGGL(k_shadow_walk, dim3(blocks), dim3(kBlock), stack_bytes(std::max(depth, (int)a.wide_cap)), s, a, depth);
+	else if (a.tree.flat_prims && count)
+		hipLaunchKernelGGL(k_shadow_flat<true>, dim3(blocks), dim3(kBlock), stack_bytes(depth), s, a, depth);
+	else if (a.tree.flat_prims)
+		hipLaunchKernelGGL(k_shadow_flat<false>, dim3(blocks), dim3(kBlock), stack_bytes(depth), s, a, depth);
 	else if (count && a.leafwise)
 		hipLaunchKernelGGL((k_shadow<true, true>), dim3(blocks), dim3(kBlock), stack_bytes(depth), s, a, depth);
 	else if (count)

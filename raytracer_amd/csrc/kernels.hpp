@@ -58,8 +58,10 @@ struct TreeRef {
 	uint32_t wide_key_base;      //   and are the bits of the float distance above this pattern (WideTraversal::distance_bits)
 	uint32_t n_loose;            // spheres, which the walk tests one by one for every ray:
 	const uint32_t *loose;       //   their primitive numbers
+	uint32_t flat_prims;         // > 0: the scene has this few primitives, and rays may test them all instead of walking a tree (traverse_flat.hpp)
 };
 
+constexpr uint32_t kFlatMaxPrims = 64;          // scenes of up to this many primitives may be scanned (TreeRef::flat_prims)
 constexpr uint32_t kWideLeaf = 0x80000000u;     // child reference of a wide node: kWideLeaf | primitive,
 constexpr uint32_t kWideNone = 0xffffffffu;     //   a node number, or kWideNone for an empty child
 constexpr float kWideMaxDir = 2.f;              // longest ray direction the wide tree's padding is computed for

@@ -211,7 +211,7 @@ typedef struct {
 	int32_t sorted;               /* the batch was traced in an order of its own making: of its rays' origins, or (packets) directions */
 	int32_t walked;               /* the batch went through the walk over the wide tree first */
 	int32_t packets;              /* ... 64 rays at a time together (a pinhole camera's batch: one origin, neighbours travel together) */
-	int32_t reserved;
+	int32_t scanned;              /* 1: the scene has so few primitives that every ray tested them all, without a tree */
 	uint64_t retraced_rays;       /* of a walked batch: rays left to the order-replaying traversal */
 	double order_ms;              /* sort keys and radix sort */
 	double walk_ms;               /* the walk's kernel */
@@ -287,6 +287,8 @@ typedef struct {
 	                                         * listed_rays, and of those that trace what the certified answers left over;
 	                                         * intersect_ms is the traversal kernel's alone */
 	uint64_t camera_launches;
+	uint64_t scanned_rays;                  /* of `rays`: answered by testing every primitive of a scene of a few dozen, without
+	                                         * a tree (retraced ones included; 0 for larger scenes) */
 } rta_stats;
 
 /* The render loop.  Replaces src/main.cpp:657-714 (row loop, per-sample ray

@@ -72,7 +72,8 @@ class Stats(C.Structure):
                 ("intersect_launches", C.c_uint64), ("shadow_launches", C.c_uint64),
                 ("early_rays", C.c_uint64), ("advance_ms", C.c_double), ("advance_launches", C.c_uint64),
                 ("retraced_rays", C.c_uint64), ("walked_rays", C.c_uint64), ("listed_rays", C.c_uint64),
-                ("cell_tests", C.c_uint64), ("camera_ms", C.c_double), ("leftover_ms", C.c_double), ("camera_launches", C.c_uint64)]
+                ("cell_tests", C.c_uint64), ("camera_ms", C.c_double), ("leftover_ms", C.c_double), ("camera_launches", C.c_uint64),
+                ("scanned_rays", C.c_uint64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -80,7 +81,7 @@ class Stats(C.Structure):
 
 class BatchStats(C.Structure):
     _fields_ = [("rays", C.c_int64), ("sorted", C.c_int32), ("walked", C.c_int32), ("packets", C.c_int32),
-                ("reserved", C.c_int32), ("retraced_rays", C.c_uint64),
+                ("scanned", C.c_int32), ("retraced_rays", C.c_uint64),
                 ("order_ms", C.c_double), ("walk_ms", C.c_double), ("replay_ms", C.c_double),
                 ("walk_node_visits", C.c_uint64), ("walk_tri_tests", C.c_uint64),
                 ("replay_node_visits", C.c_uint64), ("replay_prim_tests", C.c_uint64)]

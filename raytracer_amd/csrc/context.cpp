@@ -487,12 +487,14 @@ int rta_upload_scene(rta_context *ctx, const rta_scene_desc *desc)
 	ctx->have_wide = false;
 	ctx->have_leaf_boxes = false;
 	WideTree wide = build_wide_tree(*desc, f.tame);
-	if (wide.certifiable) {
-		// what certifies an answer found without the reference's tree: by the walk, or from a camera's cell lists
+	ctx->have_flat_boxes = false;
+	if (wide.boxes_complete) {
+		// what certifies an answer found without the reference's tree: by the walk, from a camera's cell lists, by
+		// the scan of a small scene
 		if ((rc = upload_vec(ctx, ctx->leaf_boxes, wide.leaf_boxes)))
 			return rc;
-		ctx->n_loose = (uint32_t)wide.spheres.size();
-		if (!wide.spheres.empty() && (rc = upload_vec(ctx, ctx->loose, wide.spheres)))
+		ctx->n_loose = wide.certifiable ? (uint32_t)wide.spheres.size() : 0u;
+		if (wide.certifiable && !wide.spheres.empty() && (rc = upload_vec(ctx, ctx->loose, wide.spheres)))
 			return rc;
 	}
 	if (wide.enabled) {
@@ -509,6 +511,7 @@ int rta_upload_scene(rta_context *ctx, const rta_scene_desc *desc)
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // the staging vectors die with this call
 	ctx->have_wide = wide.enabled;
 	ctx->have_leaf_boxes = wide.certifiable;
+	ctx->have_flat_boxes = wide.boxes_complete;
 	if (getenv("RTA_WIDE_VERBOSE"))
 		fprintf(stderr, "wide tree: %s%s, %u nodes, depth %d, padding/extent %.4f, reach %g\n", wide.enabled ? "built" : "none: ",
 		        wide.why_not.c_str(), wide.n_nodes, wide.depth, wide.mean_pad_over_extent, wide.reach);
@@ -603,6 +606,19 @@ static int tracing_order(rta_context *ctx, const float *d_rays, int64_t n, const
 	return RTA_OK;
 }
 
+// > 0: the scene is one that rays scan instead of walking a tree (traverse_flat.hpp) - a few dozen primitives, no wide
+// tree, and what certifying an answer needs (a tame tree, its leaves' boxes) - and has this many primitives
+static uint32_t flat_prims_of(const rta_context *ctx)
+{
+	static const char *flat = getenv("RTA_FLAT");      // measurement: 0 never, 1 only scenes without a wide tree, 2 whenever possible
+	// (960 x 540 x 64 spp frames of scenes of 12 / 25 / 34 / 50 / 63 primitives that do have a wide tree: 3.33 / 4.82 / 5.38 /
+	// 6.28 / 6.02 ms scanned, 3.76 / 5.21 / 5.89 / 6.98 / 6.73 ms walked)
+	const int mode = flat ? atoi(flat) : 2;
+	const bool scan = mode != 0 && (mode == 2 || !ctx->have_wide) && ctx->n_prims > 0 && ctx->n_prims <= (int32_t)kFlatMaxPrims &&
+	                  ctx->have_flat_boxes && ctx->tame;
+	return scan ? (uint32_t)ctx->n_prims : 0u;
+}
+
 // rta_trace_closest; `walk`: the batch goes through the certified walk first where the scene has a wide tree
 // (not in the public header: the probe library asks for the batch without the walk)
 int rta_internal_trace_closest(rta_context *ctx, const float *rays, int64_t n, rta_hit *hits, int mem, int walk)
@@ -638,12 +654,16 @@ int rta_internal_trace_closest(rta_context *ctx, const float *rays, int64_t n, r
 	HIP_TRY(ctx, hipEventRecord(ctx->batch_ev[0], s));
 	const uint32_t *order = nullptr;
 	bool packets = false;
-	if (int rc = tracing_order(ctx, d_rays, n, order, packets, true))
-		return rc;
+	static const bool exact_only = getenv("RTA_BATCH_EXACT") != nullptr;      // measurement: price the walk
+	// (a scene that is scanned: every ray meets every primitive, in whatever order the rays come)
+	TreeRef tree = tree_of(ctx);
+	tree.flat_prims = walk && n < ((int64_t)1 << 32) && !exact_only ? flat_prims_of(ctx) : 0u;
+	if (!tree.flat_prims)
+		if (int rc = tracing_order(ctx, d_rays, n, order, packets, true))
+			return rc;
 	if (packets_mode(ctx) == 2)
 		packets = true;           // (forced: whatever order the batch is traced in, 64 of its rays at a time)
 	bs.sorted = order != nullptr;
-	static const bool exact_only = getenv("RTA_BATCH_EXACT") != nullptr;      // measurement: price the walk
 	static const int cap = batch_walk_cap();
 	// the work counts of a counting call: group 0's counters, which no render is using meanwhile
 	Counters *cnt = count_work ? ctx->counters.as<Counters>() : nullptr;
@@ -661,15 +681,21 @@ int rta_internal_trace_closest(rta_context *ctx, const float *rays, int64_t n, r
 		HIP_TRY(ctx, hipMemsetAsync(cnt, 0, sizeof(Counters), s));
 	// the list of the rays the walk hands on: 4 bytes per ray; without room for it the batch is traced as before
 	const size_t list_bytes = ((size_t)n * 4 + 255) & ~(size_t)255;
-	if (walk && ctx->have_wide && n < ((int64_t)1 << 32) && !exact_only && ctx->doubts.reserve(list_bytes + 256) != hipSuccess) {
+	if (walk && (ctx->have_wide || tree.flat_prims) && n < ((int64_t)1 << 32) && !exact_only && ctx->doubts.reserve(list_bytes + 256) != hipSuccess) {
 		(void)hipGetLastError();
 		walk = false;
+		tree.flat_prims = 0;
+		if (int rc = tracing_order(ctx, d_rays, n, order, packets, true))
+			return rc;
 	}
 	HIP_TRY(ctx, hipEventRecord(ctx->batch_ev[1], s));
-	if (walk && ctx->have_wide && n < ((int64_t)1 << 32) && !exact_only) {
-		// the certified walk answers what it can prove; the rest goes through the replaying traversal
+	if (walk && (ctx->have_wide || tree.flat_prims) && n < ((int64_t)1 << 32) && !exact_only) {
+		// the certified walk (or the scan of a small scene) answers what it can prove; the rest goes through the
+		// replaying traversal
 		uint32_t *list = ctx->doubts.as<uint32_t>(), *count = (uint32_t *)(ctx->doubts.as<char>() + list_bytes);
-		if (packets) {
+		if (tree.flat_prims)
+			launch_batch_flat(s, tree, d_rays, (uint64_t)n, d_hits, list, count, cnt);
+		else if (packets) {
 			launch_batch_packet(s, tree_of(ctx), d_rays, (uint64_t)n, d_hits, order, list, count, cnt);
 			bs.packets = 1;
 		} else
@@ -682,7 +708,8 @@ int rta_internal_trace_closest(rta_context *ctx, const float *rays, int64_t n, r
 		HIP_TRY(ctx, counted(bs.walk_node_visits, bs.walk_tri_tests));
 		if (cnt)
 			HIP_TRY(ctx, hipMemsetAsync(cnt, 0, sizeof(Counters), s));
-		bs.walked = 1;
+		bs.walked = tree.flat_prims ? 0 : 1;
+		bs.scanned = tree.flat_prims ? 1 : 0;
 		bs.retraced_rays = in_doubt;
 		if (in_doubt)
 			launch_batch_closest(s, tree_of(ctx), d_rays, (uint64_t)in_doubt, d_hits, ctx->stack_depth, cnt, list);
@@ -739,10 +766,15 @@ int rta_trace_occluded(rta_context *ctx, const float *rays, const float *tmax, i
 	}
 	const uint32_t *order = nullptr;
 	bool packets = false;
-	if (int rc = tracing_order(ctx, d_rays, n, order, packets, false))
-		return rc;
 	static const bool exact_only = getenv("RTA_BATCH_EXACT") != nullptr;      // measurement: price the walk
-	if (ctx->have_wide && n < ((int64_t)1 << 32) && !exact_only)
+	TreeRef tree = tree_of(ctx);
+	tree.flat_prims = exact_only ? 0u : flat_prims_of(ctx);
+	if (!tree.flat_prims)
+		if (int rc = tracing_order(ctx, d_rays, n, order, packets, false))
+			return rc;
+	if (tree.flat_prims)
+		launch_batch_occluded_flat(ctx->stream, tree, d_rays, d_tmax, (uint64_t)n, d_out, ctx->stack_depth);
+	else if (ctx->have_wide && n < ((int64_t)1 << 32) && !exact_only)
 		launch_batch_occluded_walk(ctx->stream, tree_of(ctx), d_rays, d_tmax, (uint64_t)n, d_out, kBatchWalkCap, ctx->stack_depth, order);
 	else
 		launch_batch_occluded(ctx->stream, tree_of(ctx), d_rays, d_tmax, (uint64_t)n, d_out, ctx->stack_depth, order);
@@ -1017,13 +1049,10 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 	// A scene of a few dozen primitives needs no tree: every ray tests them all, in lock-step and mostly without
 	// divisions (traverse_flat.hpp); answers are certified against the leaves' boxes as the walk's are.  (The queues
 	// are those of the leafwise kernels.)
-	{
-		static const char *flat = getenv("RTA_FLAT");      // measurement
-		const bool scan = !base.wide_cap && ctx->n_prims <= (int64_t)kFlatMaxPrims && ctx->have_leaf_boxes && ctx->tame &&
-		                  !(p->flags & RTA_RENDER_EXACT_ONLY) && (flat ? atoi(flat) != 0 : true);
-		base.tree.flat_prims = scan ? (uint32_t)ctx->n_prims : 0u;
-		if (scan)
-			base.leafwise = 1u;
+	base.tree.flat_prims = (p->flags & RTA_RENDER_EXACT_ONLY) ? 0u : flat_prims_of(ctx);
+	if (base.tree.flat_prims) {
+		base.leafwise = 1u;
+		base.wide_cap = 0u;
 	}
 	// Camera rays join them when the camera (a pinhole) lies within the wide tree's reach; each starts
 	// with the triangle that the slot's last camera ray hit: the same pixel, most often the same triangle
@@ -1377,6 +1406,7 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 			st.walked_rays += c.walked;
 			st.listed_rays += c.listed;
 			st.cell_tests += c.cell_tests;
+			st.scanned_rays += c.scanned;
 		}
 		// all groups are idle here (synchronised above)
 		if (d_frame && n_owned)

@@ -56,6 +56,7 @@ struct rta_context {
 	rta::DeviceBuffer pairs, prims, shade_prims, materials, lights, ref_nodes;
 	rta::DeviceBuffer wide_nodes, leaf_boxes;     // the 4-wide tree of the certified traversal (wide_tree.hpp)
 	bool have_wide = false;
+	bool have_flat_boxes = false;                 // leaf_boxes alone is there (a scene with more spheres than `loose` lists)
 	bool have_leaf_boxes = false;                 // leaf_boxes and loose are there (with a wide tree, and where only the tree was refused)
 	float wide_center[3] = {0, 0, 0}, wide_reach2 = 0, wide_reach = 0;
 	int wide_depth = 0;

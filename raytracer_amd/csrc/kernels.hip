@@ -685,6 +685,8 @@ RTA_DEV void step_housekeeping(const RenderArgs &a, int par)
 			atomicAdd(&a.cnt->walked, (unsigned long long)n);
 		if (n && a.camera_cells && threadIdx.x % kRayKinds == (uint32_t)kCameraRays)
 			atomicAdd(&a.cnt->listed, (unsigned long long)n);
+		if (n && a.tree.flat_prims && (threadIdx.x % kRayKinds == (uint32_t)kBounceRays || (!a.camera_cells && threadIdx.x % kRayKinds == (uint32_t)kCameraRays)))
+			atomicAdd(&a.cnt->scanned, (unsigned long long)n);
 		a.cnt->n_ray[ray_queue_index(par ^ 1, 0, 0) + threadIdx.x] = 0;
 	}
 	if (threadIdx.x < 2 * kShards)
@@ -1533,6 +1535,66 @@ __global__ __launch_bounds__(kBlock) void k_batch_packet(const DeviceTree tree, 
 		count_flush(cnt, wc);
 }
 
+// The same batch for a scene of a few dozen primitives (TreeRef::flat_prims): one ray per lane, every primitive
+// tested (traverse_flat.hpp); rays that need the division-based box test are in doubt from the start.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_batch_flat(const DeviceTree tree, const float *rays, uint64_t n, rta_hit *hits,
+                                                       uint32_t *doubts, uint32_t *n_doubts, Counters *cnt)
+{
+	const uint64_t number = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+	const bool mine = number < n;
+	Ray ray = {mk(0, 0, 0), mk(1, 1, 1)};
+	if (mine) {
+		const float *r = rays + (size_t)number * 6;
+		ray = Ray{mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5])};
+	}
+	const bool tame = ray_is_tame(ray);
+	WorkCount wc = {0, 0, 0};
+	HitRec h;
+	bool doubt;
+	scan_flat<false, COUNT>(tree, mine && tame, ray, FLT_MAX, h, doubt, wc);
+	doubt = mine && (doubt || !tame);
+	if (mine && !doubt)
+		hits[number] = rta_hit{h.prim, h.t, h.u, h.v};
+	const unsigned long long handed_on = __ballot(doubt);
+	if (handed_on) {
+		uint32_t base = 0;
+		if ((threadIdx.x & 63) == (uint32_t)__builtin_ctzll(handed_on))
+			base = atomicAdd(n_doubts, (uint32_t)__popcll(handed_on));
+		base = (uint32_t)__shfl((int)base, __builtin_ctzll(handed_on));
+		if (doubt)
+			doubts[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(handed_on >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)handed_on, 0u))] =
+			    (uint32_t)number;
+	}
+	if (COUNT)
+		count_flush(cnt, wc);
+}
+
+// Occlusion queries likewise; what the scan leaves in doubt is traced by the replaying traversal on the spot.
+__global__ __launch_bounds__(kBlock) void k_batch_occluded_flat(const DeviceTree tree, const float *rays, const float *tmax,
+                                                                uint64_t n, uint8_t *out, const int depth)
+{
+	extern __shared__ uint32_t lds_stack[];
+	const uint64_t number = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+	const bool mine = number < n;
+	Ray ray = {mk(0, 0, 0), mk(1, 1, 1)};
+	float limit = 0.f;
+	if (mine) {
+		const float *r = rays + (size_t)number * 6;
+		ray = Ray{mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5])};
+		limit = tmax[number];
+	}
+	const bool tame = ray_is_tame(ray);
+	WorkCount wc = {0, 0, 0};
+	HitRec h;
+	bool doubt;
+	scan_flat<true, false>(tree, mine && tame, ray, limit, h, doubt, wc);
+	if (mine && (doubt || !tame))
+		traverse_dyn<true, false>(tree, ray, limit, lds_stack + threadIdx.x, depth, h, wc);
+	if (mine)
+		out[number] = h.prim >= 0 ? 1 : 0;
+}
+
 __global__ __launch_bounds__(kBlock) void k_batch_occluded(const DeviceTree tree, const float *rays, const float *tmax,
                                                            uint64_t n, uint8_t *out, const int depth,
                                                            const uint32_t rays_per_lane, const uint32_t *order)
@@ -1749,6 +1811,22 @@ void launch_batch_walk(hipStream_t s, const TreeRef &tree, const float *rays, ui
 	else
 		hipLaunchKernelGGL(k_batch_walk<false>, grid, dim3(kBlock), stack_bytes(cap), s, tree, rays, n, hits, cap, rays_per_lane,
 		                   order, doubts, n_doubts, cnt);
+}
+
+void launch_batch_flat(hipStream_t s, const TreeRef &tree, const float *rays, uint64_t n, rta_hit *hits, uint32_t *doubts,
+                       uint32_t *n_doubts, Counters *cnt)
+{
+	(void)hipMemsetAsync(n_doubts, 0, sizeof(uint32_t), s);
+	if (cnt)
+		hipLaunchKernelGGL(k_batch_flat<true>, dim3(blocks_for(n)), dim3(kBlock), 0, s, tree, rays, n, hits, doubts, n_doubts, cnt);
+	else
+		hipLaunchKernelGGL(k_batch_flat<false>, dim3(blocks_for(n)), dim3(kBlock), 0, s, tree, rays, n, hits, doubts, n_doubts, cnt);
+}
+
+void launch_batch_occluded_flat(hipStream_t s, const TreeRef &tree, const float *rays, const float *tmax, uint64_t n, uint8_t *out,
+                                int depth)
+{
+	hipLaunchKernelGGL(k_batch_occluded_flat, dim3(blocks_for(n)), dim3(kBlock), stack_bytes(depth), s, tree, rays, tmax, n, out, depth);
 }
 
 void launch_batch_packet(hipStream_t s, const TreeRef &tree, const float *rays, uint64_t n, rta_hit *hits, const uint32_t *order,

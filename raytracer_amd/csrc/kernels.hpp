@@ -38,6 +38,7 @@ struct Counters {
 	uint32_t retired[kShards];
 	unsigned long long listed;              // camera rays answered from their cell's triangle list (retraced ones included)
 	unsigned long long cell_tests;          // RTA_RENDER_COUNT_WORK only: triangle tests of those (also counted in `tri`)
+	unsigned long long scanned;             // closest-hit queries that tested every primitive of a small scene (retraced ones included)
 };
 
 struct TreeRef {
@@ -198,6 +199,11 @@ void launch_batch_closest(hipStream_t s, const TreeRef &tree, const float *rays,
 // (`cnt`: null, or where the walk adds its node visits and triangle tests)
 void launch_batch_walk(hipStream_t s, const TreeRef &tree, const float *rays, uint64_t n, rta_hit *hits, int cap,
                        const uint32_t *order, uint32_t *doubts, uint32_t *n_doubts, Counters *cnt = nullptr);
+// the same for a scene that rays scan (tree.flat_prims > 0; traverse_flat.hpp); n < 2^32
+void launch_batch_flat(hipStream_t s, const TreeRef &tree, const float *rays, uint64_t n, rta_hit *hits, uint32_t *doubts,
+                       uint32_t *n_doubts, Counters *cnt = nullptr);
+void launch_batch_occluded_flat(hipStream_t s, const TreeRef &tree, const float *rays, const float *tmax, uint64_t n, uint8_t *out,
+                                int depth);
 // the same by packets of 64 rays that walk the tree together (traverse_packet.hpp): consecutive rays of the batch, or
 // of `order`; n < 2^32
 void launch_batch_packet(hipStream_t s, const TreeRef &tree, const float *rays, uint64_t n, rta_hit *hits, const uint32_t *order,

@@ -851,6 +851,7 @@ int upload_scene_on_device(rta_context *ctx, const rta_scene_desc &d)
 	// the context's view of the scene, as rta_upload_scene's host path sets it
 	ctx->have_wide = wide.enabled;
 	ctx->have_leaf_boxes = wide.enabled;      // (this path certifies by the wide tree's conditions only)
+	ctx->have_flat_boxes = false;            // (and serves scenes far beyond the size that is scanned)
 	if (wide.enabled) {
 		memcpy(ctx->wide_center, wide.center, 12);
 		ctx->wide_reach2 = wide.reach * wide.reach * (1.f - 0x1p-20f);

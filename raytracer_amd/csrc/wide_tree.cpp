@@ -315,6 +315,7 @@ WideTree build_wide_tree(const rta_scene_desc &d, bool tame)
 	// box must lie inside its parent's (the root's own box is never tested, src/main.cpp:338-385)
 	w.leaf_boxes.assign((size_t)d.n_prims * 2, make_float4(0, 0, 0, 0));
 	std::vector<int32_t> covered;      // the primitives that some leaf holds
+	bool too_many_spheres = false;
 	{
 		std::vector<int32_t> todo = {0};
 		while (!todo.empty()) {
@@ -330,8 +331,9 @@ WideTree build_wide_tree(const rta_scene_desc &d, bool tame)
 					if (d.prim_type[p] != RTA_PRIM_TRIANGLE) {
 						// a few spheres stay outside the tree and are tested for every ray
 						if (w.spheres.size() == kWideMaxSpheres)
-							return refuse("more spheres than the walk tests one by one");
-						w.spheres.push_back(p);
+							too_many_spheres = true;      // (the boxes are still wanted: a small scene is scanned, spheres and all)
+						else
+							w.spheres.push_back(p);
 						continue;
 					}
 					for (int k = 0; k < 9; k++)
@@ -354,6 +356,9 @@ WideTree build_wide_tree(const rta_scene_desc &d, bool tame)
 
 	// the leaf boxes are complete and nested, the spheres few: answers can be certified (step 3 of the walk's
 	// proof) whether or not the scene gets a wide tree
+	w.boxes_complete = true;
+	if (too_many_spheres)
+		return refuse("more spheres than the walk tests one by one");
 	w.certifiable = true;
 	if (covered.size() < 2)
 		return refuse("fewer than two triangles");

@@ -17,6 +17,7 @@ namespace rta {
 
 struct WideTree {
 	bool enabled = false;
+	bool boxes_complete = false;      // leaf_boxes holds every primitive's leaf, and the reference's boxes are nested
 	bool certifiable = false;         // leaf_boxes and spheres are complete (also where the tree itself was refused)
 	std::string why_not;              // when !enabled
 	// 4 x 16 bytes per node (one 64-byte line): twelve words of binary16 planes of the four

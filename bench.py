@@ -70,7 +70,7 @@ WORKLOADS = {
     "dragon1080p": dict(scene="dragon.txt", width=1920, height=1080, spp=1024, survey_bytes_per_ray=691.0,
                         sps=8, cpu_spp=256, label="scenes/dragon.txt 1920x1080 1024spp"),
     "cornell1080p": dict(scene="cornell_box.txt", width=1920, height=1080, spp=256, survey_bytes_per_ray=764.0,
-                         sps=16, cpu_spp=64, label="scenes/cornell_box.txt 1920x1080 256spp", kernel="k_intersect_leafwise"),
+                         sps=16, cpu_spp=64, label="scenes/cornell_box.txt 1920x1080 256spp", kernel="k_intersect_flat"),
     "dragon4k": dict(scene="dragon.txt", width=3840, height=2160, spp=4096, survey_bytes_per_ray=691.0,
                      sps=32, cpu_spp=64, label="scenes/dragon.txt 3840x2160 4096spp"),
     "soup10m": dict(tris=10_000_000, rays=64 * 1024 * 1024, cpu_rays=4 << 20,
@@ -381,10 +381,11 @@ def bench_render(args, env):
         tot = {k: sum(st[k] for st in stats) for k in stats[0]}
         mx, sm, per_rank = over_ranks(
             [tot["gpu_ms"] / max(args.steps, 1), elapsed, float(tot["rays"] + tot["shadow_rays"]), float(tot["samples"]),
-             float(tot["rays"] - tot["early_rays"] + tot["shadow_rays"]), float(tot["retraced_rays"]), float(tot["walked_rays"])],
+             float(tot["rays"] - tot["early_rays"] + tot["shadow_rays"]), float(tot["retraced_rays"]), float(tot["walked_rays"]),
+             float(tot["scanned_rays"])],
             dev, dist)
         return dict(elapsed=mx[1], queries=sm[2], samples=sm[3], traced=sm[4], spp=spp, retraced=sm[5], walked=sm[6],
-                    rank_render_ms=per_rank)
+                    scanned=sm[7], rank_render_ms=per_rank)
 
     spp_weak = spp_fixed * world
     main_run = run(spp_fixed if args.scaling == "strong" else spp_weak)
@@ -448,9 +449,14 @@ def bench_render(args, env):
             "traced_fraction": main_run["traced"] / main_run["queries"],
             "retraced_rays_per_step": main_run["retraced"] / args.steps,
             "walked_rays_per_step": main_run["walked"] / args.steps,
+            "scanned_rays_per_step": main_run["scanned"] / args.steps,
             "traversal": ("certified walk over the wide tree (bounce and shadow rays), a pinhole camera's rays from the "
                           "triangle lists of their cells on the image plane, order-replaying traversal for the few they leave over"
                           if main_run["walked"] else
+                          "every ray tests every primitive of this small scene, without divisions, and its answer is certified "
+                          "against the reference's leaf boxes (bounce and shadow rays); a pinhole camera's rays from the triangle "
+                          "lists of their cells on the image plane; order-replaying traversal for the few they leave over"
+                          if main_run.get("scanned") else
                           "order-replaying traversal (no wide tree for this scene, or --exact-only); a pinhole camera's rays "
                           "from the triangle lists of their cells on the image plane unless --exact-only"),
             "samples_per_s": m["samples_per_s"],

@@ -362,7 +362,9 @@ RTA_DEV bool shade_hit(const RenderArgs &a, const uint32_t slot, const uint32_t 
 // neither array is read for it, and a sample that ends in the pass it was shaded
 // in never writes them.  `par`: parity of the step whose intersect launch traces
 // the rays queued here.
-__global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const int par)
+// LIGHTS = false: for scenes known to have no light (less code in the shading, fewer registers, more waves per SIMD)
+template <bool LIGHTS>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LIGHTS ? 6 : 8, LIGHTS ? 6 : 8))) void k_advance(const RenderArgs a, const int par)
 {
 	uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
 	const uint32_t lane = threadIdx.x & 63;
@@ -456,10 +458,10 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 			if (bounce > 0 || !pinhole(a))
 				r0 = a.ray0[slot];
 			float next_pdf = 0.f;
-			alive = shade_hit(a, slot, bounce, Ray{xyz(r0), xyz(r1)}, r0.w, H, rng, thr, color, next_ray, next_pdf, shadow);
+			alive = shade_hit<LIGHTS>(a, slot, bounce, Ray{xyz(r0), xyz(r1)}, r0.w, H, rng, thr, color, next_ray, next_pdf, shadow);
 			if (alive) {
 				// (with lights nearly every path gathers at once: not worth the test)
-				const bool gathered = a.n_lights > 0 || ((__float_as_uint(color.x) | __float_as_uint(color.y) | __float_as_uint(color.z)) != 0);
+				const bool gathered = LIGHTS || ((__float_as_uint(color.x) | __float_as_uint(color.y) | __float_as_uint(color.z)) != 0);
 				a.ray0[slot] = make_float4(next_ray.o.x, next_ray.o.y, next_ray.o.z, next_pdf);
 				a.ray1[slot] = make_float4(next_ray.d.x, next_ray.d.y, next_ray.d.z, __uint_as_float((bounce + 1) | (gathered ? kHasColour : 0u)));
 				a.thr[slot] = f4(thr, 0.f);
@@ -468,7 +470,7 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 		if (alive || shadow.wanted) {
 			// the radiance so far is needed again: by the next bounce, or by the
 			// occlusion query that may add the light's share to it (nothing to keep while it is 0)
-			if (a.n_lights > 0 || ((__float_as_uint(color.x) | __float_as_uint(color.y) | __float_as_uint(color.z)) != 0))
+			if (LIGHTS || ((__float_as_uint(color.x) | __float_as_uint(color.y) | __float_as_uint(color.z)) != 0))
 				a.col[slot] = f4(color, 0.f);
 			if (!alive)
 				state = kEnded;         // retired by the next pass, after k_shadow has run
@@ -657,7 +659,7 @@ __global__ __launch_bounds__(kBlock) void k_advance(const RenderArgs a, const in
 	// camera rays are coherent (a wave's rays cross one tile), bounce rays are not:
 	// they are queued apart so that a traversal wave holds rays of one kind
 	ray_queues_push(a, par, need_ray, alive, slot, next_ray, make_float4(held.u1, held.u2, __uint_as_float(sky_pixel), 0.f));
-	if (a.n_lights > 0) {
+	if (LIGHTS) {
 		const uint32_t shard = blockIdx.x % kShards;
 		const uint32_t at_sh = queue_push(shadow.wanted, &a.cnt->n_shadow[shard]);
 		if (shadow.wanted) {
@@ -811,7 +813,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 // sub-queues its camera ray came from (the slot's own, see ray_queues_push), so no sub-queue receives more than
 // its slots.
 template <bool COUNT, bool LIGHTS>
-__global__ __launch_bounds__(kBlock) void k_camera_cells(const RenderArgs a, const int par)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LIGHTS ? 7 : 8, LIGHTS ? 7 : 8))) void k_camera_cells(const RenderArgs a, const int par)
 {
 	const uint32_t shard = blockIdx.x % kShards, part = blockIdx.x / kShards;
 	const uint32_t q = ray_queue_index(par, kCameraRays, shard);
@@ -1669,7 +1671,10 @@ void launch_part_weights(hipStream_t s, const RenderArgs &a, uint32_t *weights, 
 
 void launch_advance(hipStream_t s, const RenderArgs &a, int par)
 {
-	hipLaunchKernelGGL(k_advance, dim3(blocks_for(a.n_slots)), dim3(kBlock), 0, s, a, par);
+	if (a.n_lights > 0)
+		hipLaunchKernelGGL(k_advance<true>, dim3(blocks_for(a.n_slots)), dim3(kBlock), 0, s, a, par);
+	else
+		hipLaunchKernelGGL(k_advance<false>, dim3(blocks_for(a.n_slots)), dim3(kBlock), 0, s, a, par);
 }
 
 void launch_sky_map(hipStream_t s, const TreeRef &tree, uint32_t n_pairs, const Projection &pr, uint32_t width,

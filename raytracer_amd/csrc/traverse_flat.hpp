@@ -97,7 +97,8 @@ RTA_DEV void scan_flat(const DeviceTree &tree, const bool active, const Ray &ray
 		const V3 rcp = mk(1.f / ray.d.x, 1.f / ray.d.y, 1.f / ray.d.z);
 		const float4 b0 = tree.leaf_boxes[2 * (size_t)prim], b1 = tree.leaf_boxes[2 * (size_t)prim + 1];
 		const float d = test_box_tame(mk(b0.x, b0.y, b0.z), mk(b1.x, b1.y, b1.z), ray, rcp, best);
-		doubt = !(d < FLT_MAX);
+		// (a primitive that no leaf holds - the reference never tests it - has no box: the exact traversal's)
+		doubt = !(d < FLT_MAX) || b0.w != 1.f;
 	}
 	hit = HitRec{prim, ANY ? 0.f : best, u, v};
 }

@@ -166,3 +166,43 @@ def test_renders_with_lights_and_spheres(gpu, seed, copies):
         assert st["retraced_rays"] < st["rays"] // 10 if not copies else st["retraced_rays"] > 0
         bgr2, acc2, st2 = gpu.render_scene(psc, seed=seed, samples_per_stream=3, flags=rta.RENDER_EXACT_ONLY)
         assert st2["scanned_rays"] == 0 and np.array_equal(bits(acc2), bits(acc))
+
+
+def test_a_primitive_that_no_leaf_holds_is_never_reported(gpu):
+    """A description may leave primitives out of every leaf; the reference never tests those.  The scan tests every
+    record, so a ray aimed at such a triangle must come back as the replaying traversal has it (which is compared with
+    the checker everywhere else): from behind the triangle, or not at all."""
+    import torch
+    osc, psc = _pair(_small_scene(9, n_tris=24, n_spheres=1, light=False))
+    a = psc.arrays()
+    leaves = np.nonzero(a["node_count"] > 1)[0]
+    assert leaves.size > 0
+    node = int(leaves[0])
+    dropped = int(a["node_index"][node] + a["node_count"][node] - 1)      # the leaf's last primitive, in the scene's order
+    a["node_count"] = a["node_count"].copy()
+    a["node_count"][node] -= 1
+    desc = rta.desc_from_arrays(a)
+    gpu.upload(desc)
+    tri = np.float32(a["prim_geom"]).reshape(-1, 9)[dropped].reshape(3, 3)
+    assert a["prim_type"][dropped] == 0
+    rng = np.random.default_rng(3)
+    n = 100_000
+    w = rng.random((n, 3)).astype(np.float32)
+    w /= w.sum(axis=1, keepdims=True)
+    target = (w @ tri).astype(np.float32)
+    origin = (rng.uniform(-1.4, 1.4, (n, 3)) * (1, 1, 0.6) + (0, 0, 1.0)).astype(np.float32)
+    d = target - origin
+    d = (d / np.linalg.norm(d.astype(np.float64), axis=1, keepdims=True)).astype(np.float32)
+    rr = np.concatenate([origin, d], axis=1).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    rt = torch.from_numpy(rr).to(dev)
+    got = torch.zeros((n, 4), dtype=torch.float32, device=dev)
+    want = torch.zeros((n, 4), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    gpu.trace_closest_device(rt.data_ptr(), n, got.data_ptr())
+    assert gpu.last_batch_stats()["scanned"] == 1
+    gpu.trace_closest_device(rt.data_ptr(), n, want.data_ptr(), exact_only=True)
+    assert gpu.last_batch_stats()["scanned"] == 0
+    g, e = got.cpu().numpy(), want.cpu().numpy()
+    assert np.array_equal(g.view(np.uint32), e.view(np.uint32))
+    assert not (e[:, 0].view(np.int32) == dropped).any()

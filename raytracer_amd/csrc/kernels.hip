@@ -1488,16 +1488,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
 		    if (finished && !doubt)
 			    hits[number] = rta_hit{h.prim, h.t, h.u, h.v};
 		    // the wave's rays in doubt join the list with one atomic (rare: most waves have none)
-		    const unsigned long long handed_on = __ballot(finished && doubt);
-		    if (handed_on) {
-			    uint32_t base = 0;
-			    if ((threadIdx.x & 63) == (uint32_t)__builtin_ctzll(handed_on))
-				    base = atomicAdd(n_doubts, (uint32_t)__popcll(handed_on));
-			    base = (uint32_t)__shfl((int)base, __builtin_ctzll(handed_on));
-			    if (finished && doubt)
-				    doubts[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(handed_on >> 32),
-				                                            __builtin_amdgcn_mbcnt_lo((uint32_t)handed_on, 0u))] = number;
-		    }
+		    const uint32_t at = queue_push(finished && doubt, n_doubts);
+		    if (finished && doubt)
+			    doubts[at] = number;
 	    });
 	if (COUNT)
 		count_flush(cnt, wc);
@@ -1522,16 +1515,9 @@ __global__ __launch_bounds__(kBlock) void k_batch_packet(const DeviceTree tree, 
 	walk_packet<COUNT>(tree, mine, ray, (uint32_t)number, wc, [&](bool finished, uint32_t which, const HitRec &h, bool doubt) {
 		if (finished && !doubt)
 			hits[which] = rta_hit{h.prim, h.t, h.u, h.v};
-		const unsigned long long handed_on = __ballot(finished && doubt);
-		if (handed_on) {
-			uint32_t base = 0;
-			if ((threadIdx.x & 63) == (uint32_t)__builtin_ctzll(handed_on))
-				base = atomicAdd(n_doubts, (uint32_t)__popcll(handed_on));
-			base = (uint32_t)__shfl((int)base, __builtin_ctzll(handed_on));
-			if (finished && doubt)
-				doubts[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(handed_on >> 32),
-				                                        __builtin_amdgcn_mbcnt_lo((uint32_t)handed_on, 0u))] = which;
-		}
+		const uint32_t at = queue_push(finished && doubt, n_doubts);
+		if (finished && doubt)
+			doubts[at] = which;
 	});
 	if (COUNT)
 		count_flush(cnt, wc);
@@ -1558,16 +1544,9 @@ __global__ __launch_bounds__(kBlock) void k_batch_flat(const DeviceTree tree, co
 	doubt = mine && (doubt || !tame);
 	if (mine && !doubt)
 		hits[number] = rta_hit{h.prim, h.t, h.u, h.v};
-	const unsigned long long handed_on = __ballot(doubt);
-	if (handed_on) {
-		uint32_t base = 0;
-		if ((threadIdx.x & 63) == (uint32_t)__builtin_ctzll(handed_on))
-			base = atomicAdd(n_doubts, (uint32_t)__popcll(handed_on));
-		base = (uint32_t)__shfl((int)base, __builtin_ctzll(handed_on));
-		if (doubt)
-			doubts[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(handed_on >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)handed_on, 0u))] =
-			    (uint32_t)number;
-	}
+	const uint32_t at = queue_push(doubt, n_doubts);
+	if (doubt)
+		doubts[at] = (uint32_t)number;
 	if (COUNT)
 		count_flush(cnt, wc);
 }

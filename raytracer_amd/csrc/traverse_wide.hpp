@@ -176,6 +176,11 @@ struct WideTraversal {
 	// between (distance_bits), or all ones for a miss.  Sorted as unsigned numbers the four keys
 	// come out as nodes nearest first, then triangles nearest first, then misses, and the keys
 	// are at once the stack and list entries.
+	//
+	// ROOT: the node is node 0, where every walk begins: its record is the same for all lanes and is read once per
+	// wave through the scalar cache (constant address space: the tree does not change while a kernel runs)
+	// instead of once per lane.
+	template <bool ROOT = false>
 	RTA_DEV void visit(const DeviceTree &tree, uint32_t *stack, WorkCount &work)
 	{
 		if (COUNT) work.inner++;
@@ -184,8 +189,19 @@ struct WideTraversal {
 		// in the order lo.x lo.y lo.z hi.x hi.y hi.z, relative to the scene's centre; then the four
 		// references.  v_fma_mix_f32 reads a binary16 half as an operand, so nothing is converted.
 		typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-		const uint4 *rec = reinterpret_cast<const uint4 *>(tree.wide) + 4 * (size_t)node;
-		const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], refs = rec[3];
+		uint4 q0, q1, q2, refs;
+		if (ROOT) {
+			typedef uint32_t Words __attribute__((ext_vector_type(4)));
+			const __attribute__((address_space(4))) Words *rec = (const __attribute__((address_space(4))) Words *)tree.wide;
+			const Words w0 = rec[0], w1 = rec[1], w2 = rec[2], w3 = rec[3];
+			q0 = make_uint4(w0.x, w0.y, w0.z, w0.w);
+			q1 = make_uint4(w1.x, w1.y, w1.z, w1.w);
+			q2 = make_uint4(w2.x, w2.y, w2.z, w2.w);
+			refs = make_uint4(w3.x, w3.y, w3.z, w3.w);
+		} else {
+			const uint4 *rec = reinterpret_cast<const uint4 *>(tree.wide) + 4 * (size_t)node;
+			q0 = rec[0], q1 = rec[1], q2 = rec[2], refs = rec[3];
+		}
 		const uint32_t nx01 = sx ? q1.z : q0.x, nx23 = sx ? q1.w : q0.y, fx01 = sx ? q0.x : q1.z, fx23 = sx ? q0.y : q1.w;
 		const uint32_t ny01 = sy ? q2.x : q0.z, ny23 = sy ? q2.y : q0.w, fy01 = sy ? q0.z : q2.x, fy23 = sy ? q0.w : q2.y;
 		const uint32_t nz01 = sz ? q2.z : q1.x, nz23 = sz ? q2.w : q1.y, fz01 = sz ? q1.x : q2.z, fz23 = sz ? q1.y : q2.w;
@@ -375,6 +391,9 @@ RTA_DEV void traverse_wide_pulling_as(const DeviceTree &tree, const uint32_t ref
 					tr.take_hint(stack, hint);
 				}
 				loaded = true;
+				// (every admitted ray's first node)
+				if (tr.node == 0u)
+					tr.template visit<true>(tree, stack, work);
 			}
 		}
 		if (__ballot(tr.busy(cap)) == 0) {

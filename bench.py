@@ -521,7 +521,10 @@ def roofline_render(w, excl, count, m):
                      "`value`",
            "frac_note": ("`achieved` prices every query at the reference traversal's algorithmic bytes; the kernel serves "
                          "them from its caches (`traffic`, `hbm_frac_from_counters`, `l2_frac`), which is how the figure "
-                         "can pass the HBM peak on a scene of a few kilobytes") if achieved > HBM_PEAK_GBS else None,
+                         "can pass the HBM peak on a scene of a few kilobytes"
+                         + ("; this scene's few dozen primitives are not traversed at all but tested one and all from scalar "
+                            "operands, and the kernel is bound by vector-ALU issue (about 75 instructions per triangle and wave, "
+                            "every lane in use)" if w.get("kernel") == "k_intersect_flat" else "")) if achieved > HBM_PEAK_GBS else None,
            "exclusive_pass": {"gpu_ms": excl["gpu_ms"], "intersect_ms": excl["intersect_ms"],
                               "camera_cells_ms": excl["camera_ms"], "camera_cells_launches": excl["camera_launches"],
                               "listed_camera_rays": excl["listed_rays"], "leftover_ms": excl["leftover_ms"],

@@ -21,35 +21,41 @@ struct BsdfSample {
 	V3 l;             // sampled direction, local frame
 };
 
-// src/shading.cpp:1-14
-RTA_DEV V3 sample_cosine(uint32_t &rng)
+// Both samplers below begin alike - two random numbers, the angle 2 pi r1, its sine and cosine - so the part they
+// share is done once for a wave whose lanes sample different lobes: the sine and cosine are binary64 polynomials.
+struct LobeDraws {
+	float r2, sin_phi, cos_phi;
+};
+
+RTA_DEV LobeDraws lobe_draws(uint32_t &rng)
 {
-	float r1 = rng_float(rng);
-	float r2 = rng_float(rng);
-	float phi = 2 * kPiF * r1;
-	float s = __builtin_sqrtf(r2);
-	float sp, cp;
-	pm_sincosf(phi, &sp, &cp);
-	float x = cp * s;
-	float y = sp * s;
-	float z = __builtin_sqrtf(1 - r2);
+	LobeDraws d;
+	const float r1 = rng_float(rng);
+	d.r2 = rng_float(rng);
+	const float phi = 2 * kPiF * r1;
+	pm_sincosf(phi, &d.sin_phi, &d.cos_phi);
+	return d;
+}
+
+// src/shading.cpp:1-14
+RTA_DEV V3 sample_cosine(const LobeDraws &d)
+{
+	float s = __builtin_sqrtf(d.r2);
+	float x = d.cos_phi * s;
+	float y = d.sin_phi * s;
+	float z = __builtin_sqrtf(1 - d.r2);
 	return mk(x, y, z);
 }
 
 // src/shading.cpp:19-37: visible-normal sampling on the spherical cap; the
 // fused multiply-add is explicit in the reference.
-RTA_DEV V3 sample_vndf(V3 v, float alpha, uint32_t &rng)
+RTA_DEV V3 sample_vndf(V3 v, float alpha, const LobeDraws &d)
 {
-	float r1 = rng_float(rng);
-	float r2 = rng_float(rng);
 	V3 vh = unit(mk(alpha * v.x, alpha * v.y, v.z));
-	float phi = 2 * kPiF * r1;
-	float z = __builtin_fmaf((1 - r2), (1 + vh.z), -vh.z);
+	float z = __builtin_fmaf((1 - d.r2), (1 + vh.z), -vh.z);
 	float st = __builtin_sqrtf(lesser(1.f, greater(0.f, 1 - z * z)));
-	float sp, cp;
-	pm_sincosf(phi, &sp, &cp);
-	float x = st * cp;
-	float y = st * sp;
+	float x = st * d.cos_phi;
+	float y = st * d.sin_phi;
 	V3 h = mk(x, y, z) + vh;
 	V3 n = unit(mk(alpha * h.x, alpha * h.y, h.z));
 	return (n * 2.f) * dot(n, v) - v;
@@ -107,7 +113,9 @@ RTA_DEV BsdfSample sample_bsdf(V3 v, const Material &m, uint32_t &rng)
 {
 	float wc, wv;
 	lobe_weights(m, wc, wv);
-	V3 l = (rng_float(rng) < wc) ? sample_cosine(rng) : sample_vndf(v, m.alpha, rng);
+	const bool cosine = rng_float(rng) < wc;
+	const LobeDraws d = lobe_draws(rng);
+	V3 l = cosine ? sample_cosine(d) : sample_vndf(v, m.alpha, d);
 	BsdfSample s;
 	s.pdf = bsdf_pdf(v, l, m);
 	s.f = bsdf_eval(v, l, m);

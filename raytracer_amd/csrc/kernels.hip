@@ -648,7 +648,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LIGHTS ?
 			a.ray0[slot] = make_float4(next_ray.o.x, next_ray.o.y, next_ray.o.z, 1.f);     // bsdf_pdf = 1
 		a.ray1[slot] = make_float4(next_ray.d.x, next_ray.d.y, next_ray.d.z, __uint_as_float(0u));     // bounce 0
 	} else if (state >= kWaiting && state != __float_as_uint(r1.w)) {
-		a.ray1[slot] = make_float4(r1.x, r1.y, r1.z, __uint_as_float(state));
+		// (a slot without a ray in flight has no use for a direction: three registers less to keep through the kernel)
+		a.ray1[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(state));
 	}
 	// rays answered above count like traced ones (each stands for one NearestHit call)
 	for (int m = 32; m >= 1; m >>= 1)

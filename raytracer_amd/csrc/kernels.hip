@@ -483,6 +483,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LIGHTS ?
 		rng = a.rng[slot];
 		ended = true;
 	}
+	// the occlusion query of the light sampled at the hit joins its queue here, not at the end of the kernel: ten
+	// registers less to keep through the loop below (every lane of the wave is here)
+	if (LIGHTS) {
+		const uint32_t shard = blockIdx.x % kShards;
+		const uint32_t at_sh = queue_push(shadow.wanted, &a.cnt->n_shadow[shard]);
+		if (shadow.wanted) {
+			float4 *e = a.shadow + 3 * ((size_t)shard * a.shard_cap + at_sh);
+			e[0] = f4(shadow.o, shadow.dist);
+			e[1] = f4u(shadow.d, slot);      // slot < n_slots here: a wanted query implies a live lane
+			e[2] = f4(shadow.c, 0.f);
+		}
+	}
 
 	// Retire, draw new streams, generate - and again, for as long as some lane's
 	// new camera sample provably ends in the sky (it cannot reach a leaf's box by
@@ -660,16 +672,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LIGHTS ?
 	// camera rays are coherent (a wave's rays cross one tile), bounce rays are not:
 	// they are queued apart so that a traversal wave holds rays of one kind
 	ray_queues_push(a, par, need_ray, alive, slot, next_ray, make_float4(held.u1, held.u2, __uint_as_float(sky_pixel), 0.f));
-	if (LIGHTS) {
-		const uint32_t shard = blockIdx.x % kShards;
-		const uint32_t at_sh = queue_push(shadow.wanted, &a.cnt->n_shadow[shard]);
-		if (shadow.wanted) {
-			float4 *e = a.shadow + 3 * ((size_t)shard * a.shard_cap + at_sh);
-			e[0] = f4(shadow.o, shadow.dist);
-			e[1] = f4u(shadow.d, slot);      // slot < n_slots here: a wanted query implies a live lane
-			e[2] = f4(shadow.c, 0.f);
-		}
-	}
 }
 
 // ------------------------------------------------------------------ intersect

@@ -140,6 +140,13 @@ RTA_DEV void exact_hit(const TriNumerators &n, float &t, float &u, float &v)
 // their approximations; a bound times this factor is no nearer than the distance it bounds.
 constexpr float kCloser = 1.f - 0x1p-19f, kFarther = 1.f + 0x1p-19f;
 
+// Records that every lane of a wave reads at the same place (a loop over all primitives, a tree's first node): read
+// through the constant address space - nothing writes them while a kernel runs - a wave-uniform address makes these
+// scalar loads, one per wave instead of one per lane.
+typedef float Quad __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) Quad *ConstQuads;
+typedef const __attribute__((address_space(4))) uint32_t *ConstWords;
+
 // src/main.cpp:281-301
 RTA_DEV float test_sphere(V3 center, float radius, const Ray &r)
 {

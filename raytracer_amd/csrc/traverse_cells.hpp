@@ -31,9 +31,9 @@ RTA_DEV void closest_from_cell(const DeviceTree &tree, const bool active, const 
 		// the spheres are in no list: each is tested, with the reference's own arithmetic
 		if (!tr.doubt)
 			for (uint32_t k = 0; k < tree.n_loose; k++) {
-				const uint32_t i = tree.loose[k];
-				const float4 *rec = tree.prims + kPrimQuads * (size_t)i;
-				const float4 p0 = rec[0], p1 = rec[1];
+				const uint32_t i = ((ConstWords)tree.loose)[k];
+				const ConstQuads rec = (ConstQuads)tree.prims + kPrimQuads * (size_t)i;
+				const Quad p0 = rec[0], p1 = rec[1];
 				const float t = test_sphere(mk(p0.x, p0.y, p0.z), p1.x, ray);
 				if (t < tr.best) {
 					tr.best = t;

@@ -21,9 +21,6 @@
 
 namespace rta {
 
-typedef float Quad __attribute__((ext_vector_type(4)));
-typedef const __attribute__((address_space(4))) Quad *ConstQuads;
-
 // Precondition: ray_is_tame(ray) on a tame tree for every active lane (`active` lanes only are answered; the
 // others run along).  hit: the reference's answer unless doubt.
 template <bool ANY, bool COUNT>

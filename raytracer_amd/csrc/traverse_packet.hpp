@@ -80,9 +80,9 @@ RTA_DEV void walk_packet(const DeviceTree &tree, const bool mine, const Ray &giv
 	int32_t prim = -1;
 	// spheres are outside the tree: each is tested with the reference's own arithmetic before the walk begins
 	for (uint32_t k = 0; k < tree.n_loose; k++) {
-		const uint32_t i = tree.loose[k];
-		const float4 *rec = tree.prims + kPrimQuads * (size_t)i;
-		const float4 p0 = rec[0], p1 = rec[1];
+		const uint32_t i = ((ConstWords)tree.loose)[k];
+		const ConstQuads rec = (ConstQuads)tree.prims + kPrimQuads * (size_t)i;
+		const Quad p0 = rec[0], p1 = rec[1];
 		const float t = alive ? test_sphere(mk(p0.x, p0.y, p0.z), p1.x, ray) : FLT_MAX;
 		if (t < best) {
 			best = t;

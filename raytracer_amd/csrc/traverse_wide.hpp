@@ -100,9 +100,10 @@ struct WideTraversal {
 		// walk begins (step 1 of the proof holds for them trivially: every one is tested).
 		if (admitted)
 			for (uint32_t k = 0; k < tree.n_loose; k++) {
-				const uint32_t i = tree.loose[k];
-				const float4 *rec = tree.prims + kPrimQuads * (size_t)i;
-				const float4 p0 = rec[0], p1 = rec[1];
+				// (the same sphere for every lane: scalar loads)
+				const uint32_t i = ((ConstWords)tree.loose)[k];
+				const ConstQuads rec = (ConstQuads)tree.prims + kPrimQuads * (size_t)i;
+				const Quad p0 = rec[0], p1 = rec[1];
 				const float t = test_sphere(mk(p0.x, p0.y, p0.z), p1.x, r);
 				if (t < best) {
 					prim = (int32_t)i;

@@ -50,8 +50,9 @@ constexpr double kWideMaxPadding = 0.03;
 // smallest reach the scene gets no wide tree.
 constexpr double kWideHopelessPadding = 0.25;
 
-// spheres a scene may have and still get a wide tree over its triangles
-constexpr size_t kWideMaxSpheres = 8;
+// spheres a scene may have and still get a wide tree over its triangles (every ray tests them all, one after the
+// other, from scalar operands: at this many they cost a ray about as much as its walk)
+constexpr size_t kWideMaxSpheres = 48;
 
 // primitives up to which the wide tree gets a surface-area-heuristic topology of its own (a host-side build,
 // O(n log n)); beyond, it keeps the reference tree's

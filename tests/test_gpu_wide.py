@@ -234,6 +234,53 @@ def test_a_few_spheres_beside_the_mesh(gpu):
     assert np.array_equal(bits(acc), bits(want_acc)) and np.array_equal(bgr, want_bgr)
 
 
+def test_forty_spheres_beside_the_mesh(gpu):
+    """Up to 48 spheres stay beside the wide tree (every ray tests each of them, from scalar operands); one more and the
+    scene goes back to the traversal that replays the reference's order.  Forty over a bumpy grid with a light: batches,
+    occlusion queries and the render against the checker, and the walk is what answered."""
+    tris = _grid_mesh(16, lambda x, y: 0.08 * np.sin(8 * x) * np.cos(6 * y))
+    body = " ".join("%r" % float(x) for x in tris.reshape(-1))
+    rng = np.random.default_rng(23)
+    centres = np.float32(rng.uniform((0.05, 0.05, 0.12), (0.95, 0.95, 0.6), (49, 3)))
+    radii = np.float32(rng.uniform(0.02, 0.07, 49))
+
+    def scene(n):
+        balls = "".join("sphere {\n\tcenter [%r %r %r]\n\tradius %r\n}\n\n" % (*map(float, c), float(r)) for c, r in zip(centres[:n], radii[:n]))
+        return ("render {\n\tcamera [0.5 0.5 2.4]\n\tlook_at [0.5 0.5 0]\n\tup [0 1 0]\n\twidth 56\n\theight 40\n\tsamples 12\n\tfov 30\n"
+                "\tsky_box_color [.3 .4 .6]\n}\n\nmaterial {\n\tcolor [0.8 0.7 0.6]\n\troughness 0.3\n\tmetallic 1\n}\n\n" + balls +
+                "material {\n\tcolor [0.7 0.8 0.6]\n\troughness 1\n}\n\ntriangle_mesh {\n\tvertices [ %s ]\n}\n\n"
+                "material {\n\tcolor [0 0 0]\n\troughness 1\n}\n\narea_light {\n\tcolor [9 9 8]\n}\n\n"
+                "triangle_mesh {\n\tvertices [ 0.4 0.4 1.0  0.6 0.4 1.0  0.5 0.6 1.05 ]\n}\n" % body)
+
+    for n, walked in ((40, True), (49, False)):
+        text = scene(n)
+        osc = orc.Scene.parse(text).build_bvh()
+        psc = rta.Scene.parse(text).build_bvh()
+        gpu.upload(psc)
+        nodes = osc.nodes()
+        lo, hi = nodes["lo"][0], nodes["hi"][0]
+        rr = raygen.random_rays(120000, lo - 0.2, hi + 0.2, seed=9 + n)
+        sel = rng.random(rr.shape[0]) < 0.5      # half of them aimed at the spheres
+        which = rng.integers(0, n, int(sel.sum()))
+        target = centres[which] + rng.standard_normal((int(sel.sum()), 3)).astype(np.float32) * (radii[which, None] * np.float32(0.7))
+        d = target - rr[sel, 0:3]
+        rr[sel, 3:6] = d / np.linalg.norm(d, axis=1, keepdims=True)
+        idx, t, u, v = osc.trace_closest(rr)
+        ok = same_hits(batch(gpu, rr), dict(prim=idx, t=t, u=u, v=v))
+        assert ok.all(), f"{n} spheres: {(~ok).sum()} rays differ"
+        assert bool(gpu.last_batch_stats()["walked"]) == walked
+        types = psc.arrays()["prim_type"]
+        assert (types[idx[idx >= 0]] != 0).sum() > 5000
+        k = rng.integers(0, 5, rr.shape[0])
+        with np.errstate(over="ignore"):
+            limit = np.where(idx >= 0, t * np.float32([0.6, 0.9999999, 1.0, 1.0000001, 1.7])[k], np.float32(3.0)).astype(np.float32)
+        assert np.array_equal(gpu.trace_occluded(rr, limit), osc.trace_occluded(rr, limit))
+        want_bgr, want_acc, cn = osc.render(orc.RNG_STREAM, orc.MATH_PM, seed=8, samples_per_stream=4)
+        bgr, acc, st = gpu.render_scene(psc, seed=8, samples_per_stream=4)
+        assert st["rays"] == cn["rays"] and st["shadow_rays"] == cn["shadow_rays"] and (st["walked_rays"] > 0) == walked
+        assert np.array_equal(bits(acc), bits(want_acc)) and np.array_equal(bgr, want_bgr)
+
+
 def test_scenes_without_a_wide_tree_render_as_before(gpu):
     """Large triangles keep a scene on the exact traversal (cornell_box.txt's walls); variant 20 says so."""
     psc = rta.Scene.load(f"{orc.SCENES}/cornell_box.txt").build_bvh()

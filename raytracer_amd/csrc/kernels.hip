@@ -1140,7 +1140,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
 	const uint32_t n = a.cnt->n_shadow[shard];
 	if (part == 0 && threadIdx.x == 0 && n)
 		atomicAdd(&a.cnt->shadow_rays, (unsigned long long)n);
-	const uint32_t begin = (part * (kBlock / 64) + threadIdx.x / 64) * 64;
+	// a wave works through rays_per_lane x 64 consecutive entries, handing its lanes new queries as they finish (a short
+	// queue is spread over more waves, as the bounce rays' is)
+	const uint32_t spread = (n + a.spread_blocks * kBlock - 1) / (a.spread_blocks * kBlock);
+	const uint32_t per_wave = 64u * (spread < a.rays_per_lane ? (spread ? spread : 1u) : a.rays_per_lane);
+	const uint32_t begin = (part * (kBlock / 64) + threadIdx.x / 64) * per_wave;
 	if (begin >= n)
 		return;
 	const float4 *queue = a.shadow + 3 * (size_t)shard * a.shard_cap;
@@ -1151,7 +1155,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
 		limit = e0.w;
 	};
 	occluded_by_walk(
-	    a.tree, lds_stack + threadIdx.x, (int)a.wide_cap, depth, OwnChunk{n - begin < 64u ? n - begin : 64u, 0u},
+	    a.tree, lds_stack + threadIdx.x, (int)a.wide_cap, depth, OwnChunk{n - begin < per_wave ? n - begin : per_wave, 0u},
 	    [&](uint32_t i, Ray &ray, float &limit) {
 		    fetch(begin + i, ray, limit);
 		    return begin + i;

@@ -71,3 +71,35 @@ def test_a_random_scene_renders_as_the_checker_has_it(gpu, seed):
     bgr2, acc2, st2 = gpu.render_scene(psc, seed=seed, samples_per_stream=sps, flags=rta.RENDER_EXACT_ONLY)
     assert st2["scanned_rays"] == 0 and st2["walked_rays"] == 0 and st2["listed_rays"] == 0
     assert np.array_equal(bits(acc2), bits(acc)) and np.array_equal(bgr2, bgr)
+
+
+@pytest.mark.parametrize("seed", range(100, 114))
+def test_ray_batches_over_a_random_scene(gpu, seed):
+    """rta_trace_closest and rta_trace_occluded over the same kind of scenes: rays from anywhere in and around the scene's
+    box, a third of them aimed at vertices of its triangles, limits around the distance of the closest hit."""
+    text, what = _scene(seed)
+    osc = orc.Scene.parse(text).build_bvh()
+    psc = rta.Scene.parse(text).build_bvh()
+    gpu.upload(psc)
+    nodes = osc.nodes()
+    lo, hi = nodes["lo"][0], nodes["hi"][0]
+    rng = np.random.default_rng(seed)
+    n = 150_000
+    o = rng.uniform(lo - 0.4, hi + 0.4, (n, 3)).astype(np.float32)
+    d = rng.standard_normal((n, 3))
+    objs = osc.objects()
+    verts = np.float32(objs["geom"][objs["type"] == 0][:, :9]).reshape(-1, 3)
+    aimed = rng.random(n) < 0.33
+    d[aimed] = verts[rng.integers(0, len(verts), int(aimed.sum()))] - o[aimed]
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    rr = np.concatenate([o, d], axis=1).astype(np.float32)
+    idx, t, u, v = osc.trace_closest(rr)
+    hits = gpu.trace_closest(rr)
+    assert np.array_equal(hits["prim"], idx), (what, int((hits["prim"] != idx).sum()))
+    hit = idx >= 0
+    assert np.array_equal(bits(hits["t"]), bits(t))
+    assert np.array_equal(bits(hits["u"][hit]), bits(u[hit])) and np.array_equal(bits(hits["v"][hit]), bits(v[hit]))
+    k = rng.integers(0, 5, n)
+    with np.errstate(over="ignore"):
+        limit = np.where(hit, t * np.float32([0.5, 0.9999999, 1.0, 1.0000001, 2.0])[k], np.float32(3.0)).astype(np.float32)
+    assert np.array_equal(gpu.trace_occluded(rr, limit), osc.trace_occluded(rr, limit)), what

@@ -1,5 +1,6 @@
 """Seeded random scenes - a handful to a few hundred triangles of mixed sizes, none to fifty spheres, with or without a
-light, pinhole and lens cameras inside and outside the geometry - rendered on the GPU and by the CPU checker: the same
+light, pinhole and lens cameras inside and outside the geometry, some scaled by up to a hundred either way and moved
+thirty scene sizes from the origin - rendered on the GPU and by the CPU checker: the same
 accumulators and image bytes, whichever of the ways to answer a ray the library picks for the scene (a scan of all
 primitives, the walk over the wide tree, lists per cell of the image plane, the order-replaying traversal), and the
 same again with all of them switched off.  The reference's loop: src/main.cpp:657-714."""
@@ -22,6 +23,10 @@ def _vec(v):
 
 def _scene(seed):
     rng = np.random.default_rng(seed)
+    # seeds from 10000 on: the whole scene scaled by up to a hundred either way and moved away from the origin (the
+    # reference's thresholds are absolute, and coordinates lose their low bits far from the origin)
+    scale = float(10.0 ** rng.uniform(-2, 2)) if seed >= 10000 else 1.0
+    shift = rng.uniform(-30, 30, 3) * scale if seed >= 10000 else np.zeros(3)
     n_tris = int(rng.choice([6, 20, 50, 70, 150, 400]))
     n_spheres = int(rng.choice([0, 0, 1, 3, 9, 30, 50]))
     light = bool(rng.integers(0, 2))
@@ -35,9 +40,10 @@ def _scene(seed):
         c = rng.uniform(-1, 1, 3) * (1, 1, 0.6) + (0, 0, 0.8)
         size = 10.0 ** rng.uniform(-1.3, -0.2)
         tris.append(tuple(np.concatenate([c + rng.uniform(-1, 1, 3) * size for _ in range(3)])))
-    body = " ".join("%r" % float(x) for x in np.float32(tris).reshape(-1))
+    place = lambda p: np.asarray(p, np.float64) * scale + shift
+    body = " ".join("%r" % float(x) for x in np.float32(place(np.float64(tris).reshape(-1, 3))).reshape(-1))
     cam = rng.uniform(-0.3, 0.3, 3) + (0, 0, 0.8) if inside else np.array([-2.8, rng.uniform(-1, 1), rng.uniform(0.4, 1.6)])
-    text = (f"render {{\n\tcamera {_vec(cam)}\n\tlook_at {_vec(rng.uniform(-0.3, 0.3, 3) + (0.4 if inside else 0, 0, 0.7))}\n"
+    text = (f"render {{\n\tcamera {_vec(place(cam))}\n\tlook_at {_vec(place(rng.uniform(-0.3, 0.3, 3) + (0.4 if inside else 0, 0, 0.7)))}\n"
             f"\twidth {int(rng.integers(24, 72))}\n\theight {int(rng.integers(16, 56))}\n\tsamples {int(rng.integers(3, 9))}\n"
             f"\tfov {float(rng.uniform(25, 80))!r}\n\tsky_box_color [.4 .5 .8]\n" + ("\tdefocus_angle 0.7\n" if lens else "") + "}\n\n")
     text += f"material {{\n\tcolor [0.7 0.7 0.6]\n\troughness {float(rng.uniform(0.1, 1))!r}\n\tmetallic {int(rng.integers(0, 2))}\n}}\n\n"
@@ -45,14 +51,15 @@ def _scene(seed):
     text += "material {\n\tcolor [0.8 0.3 0.2]\n\troughness 0.25\n\tmetallic 1\n}\n\n"
     for _ in range(n_spheres):
         c = rng.uniform(-0.9, 0.9, 3) * (1, 1, 0.5) + (0, 0, 0.7)
-        text += f"sphere {{\n\tcenter {_vec(c)}\n\tradius {float(rng.uniform(0.03, 0.25))!r}\n}}\n\n"
+        text += f"sphere {{\n\tcenter {_vec(place(c))}\n\tradius {float(rng.uniform(0.03, 0.25)) * scale!r}\n}}\n\n"
     if light:
-        text += ("material {\n\tcolor [0 0 0]\n}\n\narea_light {\n\tcolor [9 8 6]\n}\n\ntriangle_mesh {\n\tvertices [ "
-                 "-0.3 -0.3 2.1  0.3 0.3 2.1  0.3 -0.3 2.1  -0.3 -0.3 2.1  -0.3 0.3 2.1  0.3 0.3 2.1 ]\n}\n\n")
+        lamp = np.float64([-0.3, -0.3, 2.1, 0.3, 0.3, 2.1, 0.3, -0.3, 2.1, -0.3, -0.3, 2.1, -0.3, 0.3, 2.1, 0.3, 0.3, 2.1]).reshape(-1, 3)
+        text += ("material {\n\tcolor [0 0 0]\n}\n\narea_light {\n\tcolor [9 8 6]\n}\n\ntriangle_mesh {\n\tvertices [ " +
+                 " ".join("%r" % float(x) for x in np.float32(place(lamp)).reshape(-1)) + " ]\n}\n\n")
     return text, dict(tris=len(tris) + (2 if light else 0), spheres=n_spheres, light=light, lens=lens, inside=inside)
 
 
-@pytest.mark.parametrize("seed", range(28))
+@pytest.mark.parametrize("seed", list(range(28)) + list(range(10000, 10016)))
 def test_a_random_scene_renders_as_the_checker_has_it(gpu, seed):
     text, what = _scene(seed)
     osc = orc.Scene.parse(text).build_bvh()
@@ -66,14 +73,14 @@ def test_a_random_scene_renders_as_the_checker_has_it(gpu, seed):
     # one of the ways to answer a ray without replaying the reference's traversal was in fact taken ...
     prims = what["tris"] + what["spheres"]
     if prims <= 64:
-        assert st["scanned_rays"] > 0 and st["walked_rays"] == 0, (what, st)
+        assert st["walked_rays"] == 0 and (st["scanned_rays"] > 0 or st["rays"] == st["samples"]), (what, st)      # (no bounce: nothing seen)
     # ... and without any of them the frame is the same
     bgr2, acc2, st2 = gpu.render_scene(psc, seed=seed, samples_per_stream=sps, flags=rta.RENDER_EXACT_ONLY)
     assert st2["scanned_rays"] == 0 and st2["walked_rays"] == 0 and st2["listed_rays"] == 0
     assert np.array_equal(bits(acc2), bits(acc)) and np.array_equal(bgr2, bgr)
 
 
-@pytest.mark.parametrize("seed", range(100, 114))
+@pytest.mark.parametrize("seed", list(range(100, 114)) + list(range(10100, 10108)))
 def test_ray_batches_over_a_random_scene(gpu, seed):
     """rta_trace_closest and rta_trace_occluded over the same kind of scenes: rays from anywhere in and around the scene's
     box, a third of them aimed at vertices of its triangles, limits around the distance of the closest hit."""

@@ -1054,14 +1054,19 @@ int rta_render(rta_context *ctx, const rta_camera *camera, const rta_render_para
 		base.leafwise = 1u;
 		base.wide_cap = 0u;
 	}
-	// Camera rays join them when the camera (a pinhole) lies within the wide tree's reach; each starts
-	// with the triangle that the slot's last camera ray hit: the same pixel, most often the same triangle
+	// Camera rays join them when the camera - all of its lens (src/main.cpp:665-669), if it has one - lies within the
+	// wide tree's reach (the walk looks at each ray's origin again: this only keeps rays that it would all hand on
+	// out of it); each starts with the triangle that the slot's last camera ray hit: the same pixel, most often the
+	// same triangle
 	{
-		double d2 = 0;
-		for (int k = 0; k < 3; k++)
+		double d2 = 0, lu2 = 0, lv2 = 0;
+		for (int k = 0; k < 3; k++) {
 			d2 += ((double)camera->origin[k] - ctx->wide_center[k]) * ((double)camera->origin[k] - ctx->wide_center[k]);
+			lu2 += (double)camera->lens_u[k] * camera->lens_u[k], lv2 += (double)camera->lens_v[k] * camera->lens_v[k];
+		}
+		const double farthest = sqrt(d2) + (camera->defocus_angle > 0.f ? sqrt(lu2) + sqrt(lv2) : 0.0);
 		static const char *camera_walk = getenv("RTA_CAMERA_WALK"), *hints = getenv("RTA_HINTS");      // measurement
-		base.camera_walk = base.wide_cap && !(camera->defocus_angle > 0.f) && d2 < 0.99 * (double)ctx->wide_reach * ctx->wide_reach &&
+		base.camera_walk = base.wide_cap && farthest * farthest < 0.99 * (double)ctx->wide_reach * ctx->wide_reach &&
 		                           (camera_walk ? atoi(camera_walk) != 0 : true)
 		                       ? 1u
 		                       : 0u;

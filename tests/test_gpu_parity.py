@@ -339,6 +339,8 @@ def test_lens_camera_on_the_dragon_bit_exact(gpu, angle, look_at):
     bgr, acc, st = gpu.render_scene(psc, seed=5, samples_per_stream=8)
     assert st["rays"] == cn["rays"]
     assert st["early_rays"] > 0.5 * st["rays"]
+    # the rest - rays from the lens as well as bounce rays - take the walk over the wide tree
+    assert st["walked_rays"] > 0.99 * (st["rays"] - st["early_rays"]), st
     same = bits(acc) == bits(want_acc)
     assert same.all(), f"{(~same).any(axis=2).sum()} pixels differ in radiance bits"
     assert np.array_equal(bgr, want_bgr)

@@ -51,11 +51,22 @@ RTA_DEV void closest_from_cell(const DeviceTree &tree, const bool active, const 
 	// One triangle per lane and trip, for as long as some lane has one left.  The entries come nearest first
 	// by the least distance at which each can be hit at all (the low word of its key): once that lies beyond
 	// the nearest hit so far, the rest of the list cannot change the answer nor tie with it.
+	// (an entry is fetched one trip ahead, together with the triangle of the trip before: one wait per trip, not two)
+	uint32_t next_prim = 0;
+	float next_bound = 0.f;
+	if (k < end) {
+		next_bound = __uint_as_float((uint32_t)cell_keys[k]);
+		next_prim = cell_list[k];
+	}
 	while (__ballot(k < end)) {
-		if (k < end && __uint_as_float((uint32_t)cell_keys[k]) > tr.best)
+		if (k < end && next_bound > tr.best)
 			k = end;
 		if (k < end) {
-			const uint32_t i = cell_list[k++];
+			const uint32_t i = next_prim;
+			if (++k < end) {
+				next_bound = __uint_as_float((uint32_t)cell_keys[k]);
+				next_prim = cell_list[k];
+			}
 			if (COUNT) work.tri++;
 			const float4 *rec = tree.prims + kPrimQuads * (size_t)i;
 			const float4 p0 = rec[0], p1 = rec[1], p2 = rec[2];
